@@ -1,0 +1,65 @@
+"""Shared helpers for the tests: golden loading, spec factories, comparison of packed gradients."""
+import os
+
+import numpy as np
+
+from oracle import aread_oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GRAD_SAMPLE_STRIDE = 37
+
+
+def spec_full(**kw):
+    base = dict(field_dims=[40, 7, 5, 9, 11, 30, 10], embed_dim=32, multi_hot_flag=[False] * 7 + [True] * 10,
+                itemid_idx=0, seq_maxlen=5, method="mean", n_tower=(3, 6, 12), n_domain=5, domain_idx=2)
+    base.update(kw)
+    return O.Spec(**base)
+
+
+def spec_tiny(**kw):
+    base = dict(field_dims=[23, 4, 6, 3, 17], embed_dim=16, multi_hot_flag=[False] * 5, itemid_idx=0,
+                method=None, n_tower=(2, 3, 5), n_domain=4, domain_idx=1, n_expert=3,
+                expert_dims=(40, 24, 12), tower_dims=((12, 8), (8, 8), (8, 4)), n_cross=2, atten_embed_dim=64)
+    base.update(kw)
+    return O.Spec(**base)
+
+
+GOLDEN_MODELS = {"full": ("aread_full.npz", spec_full, 123), "tiny": ("aread_tiny.npz", spec_tiny, 321)}
+
+_cache = {}
+
+
+def load_golden(name):
+    if name not in _cache:
+        with np.load(os.path.join(GOLDEN, name)) as z:
+            _cache[name] = {k: z[k] for k in z.files}
+    return _cache[name]
+
+
+def golden_masks(spec, G, which):
+    return [O.unpack_mask(spec, row) for row in G[f"masks/{which}"]]
+
+
+def check_grads(G, prefix, grads, rtol=2e-4, atol_scale=2e-5, skip=(), floor=2e-8):
+    """Compare a dict name->array with packed golden gradients (full / strided sample + sums)."""
+    n = 0
+    for key in G:
+        if not key.startswith(prefix + "/full/") and not key.startswith(prefix + "/samp/"):
+            continue
+        name = key[len(prefix) + 6:]
+        if name in skip or name not in grads:
+            continue
+        got = np.asarray(grads[name], dtype=np.float32).reshape(-1)
+        ref = G[key]
+        if key.startswith(prefix + "/samp/"):
+            sums = G[f"{prefix}/sum/{name}"]
+            scale = max(float(sums[1]) / got.size, 1e-12)
+            np.testing.assert_allclose(got[::GRAD_SAMPLE_STRIDE], ref, rtol=rtol, atol=max(floor, atol_scale * max(scale, np.abs(ref).max())),
+                                       err_msg=name)
+            assert abs(got.astype(np.float64).sum() - sums[0]) <= 1e-3 * max(sums[1], 1e-9), name
+        else:
+            atol = max(floor, atol_scale * float(np.abs(ref).max()))  # pre-BN bias grads are ~1e-10 noise
+            np.testing.assert_allclose(got, ref, rtol=rtol, atol=atol, err_msg=name)
+        n += 1
+    assert n > 0, f"no golden gradients under {prefix}"
+    return n
