@@ -1,0 +1,9 @@
+"""aread_amd -- MI355X-native (gfx950) implementation of AREAD's CTR forward/backward hot path.
+
+The package mirrors the reference's module interface for that path only (model/layer.py,
+model/aread.py); the compute lives in libaread_hip.so behind the C ABI of include/aread_hip.h."""
+from . import _lib                                  # noqa: F401
+from .layer import FeaturesEmbedding                # noqa: F401
+from .plan import RowPlan                           # noqa: F401
+
+__all__ = ["FeaturesEmbedding", "RowPlan"]

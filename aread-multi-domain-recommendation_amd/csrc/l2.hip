@@ -1,0 +1,78 @@
+// l2.hip -- dense L2 regulariser of the embedding table: one streaming pass that produces both
+// sum(w^2) (block partials, reduced in fixed order) and the dense gradient 2*l2*w.
+// Replaces the table term of BaseModel.get_regularization_loss (model/layer.py:96-112).
+// HBM-bound: reads n*4 bytes, writes n*4 bytes; 16 B per lane, grid-stride over 2048 workgroups.
+#include "common.h"
+
+#define L2_THREADS 256
+#define L2_BLOCKS 2048
+
+__global__ __launch_bounds__(L2_THREADS) void k_l2_table(const float* __restrict__ w, int64_t n, float gscale,
+                                                         float* __restrict__ grad, float* __restrict__ partial) {
+    const int64_t n4 = n >> 2;
+    const float4* w4 = (const float4*)w;
+    float4* g4 = (float4*)grad;
+    float acc = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * L2_THREADS;
+    for (int64_t i = (int64_t)blockIdx.x * L2_THREADS + threadIdx.x; i < n4; i += stride) {
+        const float4 v = w4[i];
+        acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        if (grad) g4[i] = make_float4(gscale * v.x, gscale * v.y, gscale * v.z, gscale * v.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {             // scalar tail
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        const float v = w[i];
+        acc += v * v;
+        if (grad) grad[i] = gscale * v;
+    }
+    if (!partial) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    __shared__ float s[L2_THREADS / WAVE];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < L2_THREADS / WAVE; ++i) t += s[i];
+        partial[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_l2_finish(const float* __restrict__ partial, int n, float l2,
+                                                   float* __restrict__ out, int accumulate) {
+    __shared__ double s[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += (double)partial[i];
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float v = (float)((double)l2 * s[0]);
+        out[0] = accumulate ? out[0] + v : v;
+    }
+}
+
+extern "C" int aread_l2_partials(void) { return L2_BLOCKS; }
+
+extern "C" int aread_l2_table(const float* w, int64_t n, float l2, float grad_scale, float* grad, float* partial,
+                              void* stream) {
+    AR_CHECK_ARG(w != nullptr && n > 0, "aread_l2_table: empty input");
+    AR_CHECK_ARG(((uintptr_t)w & 15) == 0 && ((uintptr_t)grad & 15) == 0, "aread_l2_table: 16-byte alignment");
+    AR_CHECK_ARG(grad || partial, "aread_l2_table: nothing to do");
+    hipLaunchKernelGGL(k_l2_table, dim3(L2_BLOCKS), dim3(L2_THREADS), 0, (hipStream_t)stream, w, n,
+                       2.0f * l2 * grad_scale, grad, partial);
+    AR_LAUNCH_CHECK();
+    return AREAD_OK;
+}
+
+extern "C" int aread_l2_finish(const float* partial, int n_partial, float l2, float* loss_out, int accumulate,
+                               void* stream) {
+    AR_CHECK_ARG(partial && loss_out && n_partial > 0, "aread_l2_finish: bad arguments");
+    hipLaunchKernelGGL(k_l2_finish, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, n_partial, l2, loss_out,
+                       accumulate);
+    AR_LAUNCH_CHECK();
+    return AREAD_OK;
+}
