@@ -5,5 +5,6 @@ model/aread.py); the compute lives in libaread_hip.so behind the C ABI of includ
 from . import _lib                                  # noqa: F401
 from .layer import FeaturesEmbedding                # noqa: F401
 from .plan import RowPlan                           # noqa: F401
+from .aread import AREAD, pack_masks                # noqa: F401
 
-__all__ = ["FeaturesEmbedding", "RowPlan"]
+__all__ = ["FeaturesEmbedding", "RowPlan", "AREAD", "pack_masks"]

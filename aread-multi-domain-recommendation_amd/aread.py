@@ -1,0 +1,493 @@
+"""Host-side mirror of the reference's model/aread.py (class AREAD) for the hot path.
+
+Same constructor, forward() signature/modes, state_dict keys and HEMP-facing attributes; the math
+runs in libaread_hip.so.  Differences that are deliberate (and documented in DESIGN.md):
+  * the dead attention branch (aread.py:139-140) is never computed; its parameters exist only so
+    that a reference checkpoint loads with strict=True;
+  * every trainable dense tensor lives in ONE flat nn.Parameter (`dense`); state_dict()/load_state_dict()
+    expose it under the reference's per-tensor keys;
+  * two extensions: mode='with_mask' is the fused multi-domain call the reference intended
+    (aread.py:203-223 raises NameError there), and train_step() is the fused, graph-capturable
+    forward + loss + backward used by bench.py.
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib as L
+from .layer import FeaturesEmbedding
+from .plan import RowPlan
+
+MAX_LEVEL, MAX_LAYER = 4, 4
+
+
+class ModelCfg(C.Structure):
+    _fields_ = [("embed_dim", C.c_int32), ("f_out", C.c_int32), ("domain_field", C.c_int32),
+                ("n_expert", C.c_int32), ("n_expert_layers", C.c_int32), ("expert_dims", C.c_int32 * MAX_LAYER),
+                ("n_level", C.c_int32), ("n_tower", C.c_int32 * MAX_LEVEL), ("n_tower_layers", C.c_int32),
+                ("tower_dims", (C.c_int32 * MAX_LAYER) * MAX_LEVEL), ("n_cross", C.c_int32), ("n_domain", C.c_int32),
+                ("dropout", C.c_float), ("l2_linear", C.c_float), ("l2_dnn", C.c_float), ("l2_cross", C.c_float)]
+
+
+class TensorDesc(C.Structure):
+    _fields_ = [("name", C.c_char * 96), ("kind", C.c_int32), ("ndim", C.c_int32), ("offset", C.c_int64),
+                ("shape", C.c_int64 * 2), ("l2", C.c_float)]
+
+
+class Call(C.Structure):
+    _fields_ = [("B", C.c_int64), ("n_seg", C.c_int32), ("mode", C.c_int32), ("train", C.c_int32),
+                ("update_running", C.c_int32), ("domain", C.c_int32), ("drop_seed", C.c_uint32),
+                ("plan", C.c_void_p), ("masks", C.c_void_p), ("params", C.c_void_p), ("stats", C.c_void_p),
+                ("nbt", C.c_void_p), ("ws", C.c_void_p), ("probs", C.c_void_p), ("gate_stats", C.c_void_p),
+                ("y", C.c_void_p), ("seg_weight", C.c_void_p), ("loss_out", C.c_void_p)]
+
+
+for _n, _r, _a in [
+    ("aread_model_create", C.c_int, [C.POINTER(ModelCfg), C.POINTER(C.c_void_p)]),
+    ("aread_model_destroy", None, [C.c_void_p]),
+    ("aread_model_param_floats", C.c_int64, [C.c_void_p]),
+    ("aread_model_stat_floats", C.c_int64, [C.c_void_p]),
+    ("aread_model_n_bn", C.c_int, [C.c_void_p]),
+    ("aread_model_n_tensors", C.c_int, [C.c_void_p]),
+    ("aread_model_tensor", C.c_int, [C.c_void_p, C.c_int, C.POINTER(TensorDesc)]),
+    ("aread_model_edge_count", C.c_int, [C.c_void_p]),
+    ("aread_model_gate_rows", C.c_int, [C.c_void_p]),
+    ("aread_model_workspace_bytes", C.c_int64, [C.c_void_p, C.c_int64, C.c_int]),
+    ("aread_model_l2_coef", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("aread_forward", C.c_int, [C.c_void_p, C.POINTER(Call), C.c_void_p, C.c_void_p]),
+    ("aread_backward", C.c_int, [C.c_void_p, C.POINTER(Call), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("aread_debug_ws_offset", C.c_int64, [C.c_void_p, C.c_int64, C.c_int, C.c_char_p]),
+    ("aread_l2_dense", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+]:
+    L.register(_n, _r, _a)
+
+
+def pack_masks(masks, n_domain, edge_count, device):
+    """list (per domain) of masks (list of n_level+1 bool tensors/arrays, or None) -> uint8 [n_domain, edges]."""
+    out = np.zeros((n_domain, edge_count), dtype=np.uint8)
+    for d, mk in enumerate(masks):
+        if mk is None:
+            continue
+        flat = np.concatenate([(m.detach().cpu().numpy() if isinstance(m, torch.Tensor) else np.asarray(m))
+                               .astype(np.uint8).reshape(-1) for m in mk])
+        if flat.size != edge_count:
+            raise ValueError(f"mask of domain {d} has {flat.size} edges, expected {edge_count}")
+        out[d] = flat
+    return torch.from_numpy(out).to(device)
+
+
+class _CallState:
+    """Everything one forward leaves behind for its backward (buffers are owned here)."""
+    __slots__ = ("plan", "e", "ws", "call", "keep", "probs", "x")
+
+
+class _AreadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, table, dense, model, x, st):
+        ctx.model, ctx.st = model, st
+        ctx.table_shape = tuple(table.shape)
+        return st.probs
+
+    @staticmethod
+    def backward(ctx, dprobs):
+        model, st = ctx.model, ctx.st
+        dprobs = dprobs.contiguous()
+        grads = torch.empty_like(model.dense)
+        de = torch.empty_like(st.e)
+        L.check(L.lib().aread_backward(model._handle, C.byref(st.call), L.ptr(st.e), L.ptr(dprobs), L.ptr(grads),
+                                       L.ptr(de), L.stream()))
+        gtab = torch.zeros(ctx.table_shape, dtype=torch.float32, device=de.device)
+        model.embedding.scatter_grad(st.x, de, gtab, st.plan.sample_row)
+        return gtab, grads, None, None, None
+
+
+class _RegFn(torch.autograd.Function):
+    """get_regularization_loss (layer.py:96-112) as one streaming pass per direction."""
+
+    @staticmethod
+    def forward(ctx, table, dense, model):
+        ctx.model = model
+        ctx.save_for_backward(table, dense)
+        out = torch.zeros(65, dtype=torch.float32, device=table.device)
+        lib = L.lib()
+        part = model._l2_partials(table.device)
+        L.check(lib.aread_l2_table(L.ptr(table), table.numel(), model.l2_reg_embedding, 1.0, None, L.ptr(part), L.stream()))
+        L.check(lib.aread_l2_finish(L.ptr(part), part.numel(), model.l2_reg_embedding, L.ptr(out), 0, L.stream()))
+        L.check(lib.aread_l2_dense(L.ptr(dense), L.ptr(model._l2_coef(table.device)), dense.numel(), None, L.ptr(out), 1,
+                                   L.stream()))
+        return out[:1].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        table, dense = ctx.saved_tensors
+        model = ctx.model
+        g = float(gout.reshape(-1)[0])      # scalar scale of the regulariser in the caller's loss
+        gtab = torch.empty_like(table)
+        L.check(L.lib().aread_l2_table(L.ptr(table), table.numel(), model.l2_reg_embedding, g, L.ptr(gtab), None, L.stream()))
+        gd = 2.0 * g * model._l2_coef(table.device) * dense.detach()
+        return gtab, gd, None
+
+
+class AREAD(nn.Module):
+    """Adaptive REcommendation for All Domains -- model/aread.py:15-322 on MI355X."""
+
+    def __init__(self, one_hot_feature_dims, embed_dim, multi_hot_dict, n_tower, n_domain, base_model,
+                 expert_dims, tower_dims, domain_idx, domain2group=None, n_cross_layers=3, dropout=0.2, device=None,
+                 l2_reg_embedding=1e-5, l2_reg_linear=1e-5, l2_reg_dnn=1e-5, l2_reg_cross=1e-5, config=None):
+        super().__init__()
+        if base_model != "mmoe":
+            raise NotImplementedError("only base_model='mmoe' is on the accelerated path (SURVEY 2.1 #11)")
+        if not getattr(config, "use_dcn", False):
+            raise ValueError("AREAD's masked path needs use_dcn=True (aread.py:231,307 use cn_out unconditionally)")
+        self.model_name = "aread"
+        self.base_model = base_model
+        self.embedding = FeaturesEmbedding(one_hot_feature_dims, embed_dim, multi_hot_dict)
+        self.embed_dim = embed_dim
+        self.embed_output_dim = self.embedding.output_dim0 * embed_dim
+        self.field_num = self.embedding.one_hot_field_num + self.embedding.multi_hot_field_num
+        self.domain_idx = domain_idx
+        self.n_tower = tuple(int(t) for t in n_tower)
+        self.n_level = len(self.n_tower)
+        self.edge_num = self.n_tower[0] + sum(self.n_tower[l - 1] * self.n_tower[l] for l in range(1, self.n_level)) \
+            + self.n_tower[-1]
+        self.n_domain = n_domain
+        self.tower_dims = tuple(tuple(int(v) for v in t) for t in tower_dims)
+        self.expert_dims = tuple(int(v) for v in expert_dims)
+        self.bottom_level = len(self.expert_dims)
+        self.device = device
+        self.domain2group = np.array([domain2group[d] for d in range(n_domain)]) if domain2group is not None else None
+        self.domain_mask = [None for _ in range(n_domain)]
+        self.candidate_domain_mask = None
+        self.tower2cluster = [[None for _ in range(self.n_tower[l])] for l in range(self.n_level)]
+        self.model_state = None
+        self.domain_tower_gate_values = None
+        self.tmp_tower_gate_values = [[None for _ in range(self.n_tower[l])] for l in range(self.n_level)]
+        self.gate_value_threshold = None
+        self.eval_loss = None
+        self.domain_size = np.array(config.domain_size[config.dataset_name])
+        self.use_dcn, self.use_atten = True, getattr(config, "use_atten", False)
+        self.dropout = float(dropout)
+        self.l2_reg_embedding, self.l2_reg_linear = float(l2_reg_embedding), float(l2_reg_linear)
+        self.l2_reg_dnn, self.l2_reg_cross = float(l2_reg_dnn), float(l2_reg_cross)
+        if domain_idx >= self.embedding.one_hot_field_num:
+            raise ValueError("domain_idx must name a one-hot column")
+
+        cfg = ModelCfg()
+        cfg.embed_dim, cfg.f_out, cfg.domain_field = embed_dim, self.embedding.output_dim0, domain_idx
+        cfg.n_expert, cfg.n_expert_layers = int(config.mmoe_n_expert), len(self.expert_dims)
+        for j, v in enumerate(self.expert_dims):
+            cfg.expert_dims[j] = v
+        cfg.n_level, cfg.n_tower_layers = self.n_level, len(self.tower_dims[0])
+        for l in range(self.n_level):
+            cfg.n_tower[l] = self.n_tower[l]
+            if len(self.tower_dims[l]) != cfg.n_tower_layers:
+                raise ValueError("every tower level must have the same number of layers")
+            for j, v in enumerate(self.tower_dims[l]):
+                cfg.tower_dims[l][j] = v
+        cfg.n_cross, cfg.n_domain, cfg.dropout = int(config.n_cross_layers), n_domain, self.dropout
+        cfg.l2_linear, cfg.l2_dnn, cfg.l2_cross = self.l2_reg_linear, self.l2_reg_dnn, self.l2_reg_cross
+        self._cfg = cfg
+        h = C.c_void_p()
+        L.check(L.lib().aread_model_create(C.byref(cfg), C.byref(h)))
+        self._handle = h
+        lib = L.lib()
+        self.n_heads = self.n_tower[-1]
+        self._edge_count = lib.aread_model_edge_count(h)
+        self._gate_rows = lib.aread_model_gate_rows(h)
+        assert self._edge_count == self.edge_num
+        self._tensors = []
+        d = TensorDesc()
+        for i in range(lib.aread_model_n_tensors(h)):
+            L.check(lib.aread_model_tensor(h, i, C.byref(d)))
+            shape = tuple(int(d.shape[k]) for k in range(d.ndim))
+            self._tensors.append((d.name.decode(), int(d.kind), int(d.offset), shape, float(d.l2)))
+        self.dense = nn.Parameter(torch.zeros(lib.aread_model_param_floats(h)))
+        self.register_buffer("bn_stats", torch.zeros(lib.aread_model_stat_floats(h)))
+        self.register_buffer("bn_nbt", torch.zeros(lib.aread_model_n_bn(h), dtype=torch.int64))
+        # parameters that never influence the output (kept for checkpoint compatibility only)
+        self.group_embedding_dead = None
+        self.final_gate = nn.Sequential(nn.Linear(2 * embed_dim, self.n_tower[-1], bias=False), nn.Softmax(dim=1))
+        if self.use_atten:
+            a = getattr(config, "atten_embed_dim", embed_dim)
+            self.atten_embedding = nn.Linear(embed_dim, a)
+            self.self_attns = nn.ModuleList([nn.MultiheadAttention(a, config.att_head_num, dropout=dropout)
+                                             for _ in range(config.att_layer_num)])
+            if config.att_res:
+                self.V_res_embedding = nn.Linear(embed_dim, a)
+            self.atten_linear = nn.Linear(self.embedding.output_dim0 * a, 1, bias=False)
+        self._init_dense()
+        self._coef, self._part, self._ws_cache = {}, {}, {}
+        self._drop_calls = 0
+        self.drop_seed_base = 0
+        self.drop_seed = None          # set to an int to pin the dropout stream (tests)
+        self._register_state_dict_hook(AREAD._sd_hook)
+        self._register_load_state_dict_pre_hook(self._load_hook)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None):
+                L.lib().aread_model_destroy(self._handle)
+        except Exception:
+            pass
+
+    # ---- parameters -----------------------------------------------------------------------------
+    def named_views(self):
+        """(reference key, tensor view) for every tensor that lives in dense / bn_stats / bn_nbt."""
+        bufs = {0: self.dense.data, 1: self.bn_stats, 2: self.bn_nbt}
+        for name, kind, off, shape, _ in self._tensors:
+            n = int(np.prod(shape)) if shape else 1
+            yield name, bufs[kind][off:off + n].view(shape)
+
+    def _init_dense(self):
+        """torch defaults of the reference's layers: Linear kaiming-uniform(a=sqrt(5)), BN gamma=1/beta=0,
+        running stats 0/1, cn.b = 0 (layer.py:525-527), Embedding N(0,1)."""
+        with torch.no_grad():
+            for name, v in self.named_views():
+                if name.endswith("running_var"):
+                    v.fill_(1.0)
+                elif name.endswith(("running_mean", "num_batches_tracked")) or name.startswith("cn.b."):
+                    v.zero_()
+                elif name == "group_embedding.weight":
+                    v.normal_()
+                elif ".layers." in name and v.dim() == 1 and name.endswith("weight"):
+                    v.fill_(1.0)                       # BatchNorm gamma
+                elif ".layers." in name and v.dim() == 1 and int(name.split(".layers.")[1].split(".")[0]) % 4 == 1:
+                    v.zero_()                          # BatchNorm beta
+                elif v.dim() == 2:
+                    bound = 1.0 / np.sqrt(v.shape[1])
+                    v.uniform_(-bound, bound)
+                else:                                  # Linear bias: U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+                    v.uniform_(-0.05, 0.05)
+
+    @staticmethod
+    def _sd_hook(self, sd, prefix, local_metadata):
+        out = OrderedDict()
+        for k, v in sd.items():
+            if k in (prefix + "dense", prefix + "bn_stats", prefix + "bn_nbt"):
+                continue
+            out[k] = v
+        bufs = {0: sd[prefix + "dense"], 1: sd[prefix + "bn_stats"], 2: sd[prefix + "bn_nbt"]}
+        for name, kind, off, shape, _ in self._tensors:
+            n = int(np.prod(shape)) if shape else 1
+            out[prefix + name] = bufs[kind][off:off + n].view(shape)
+        sd.clear()
+        sd.update(out)
+        return sd
+
+    def _load_hook(self, sd, prefix, local_metadata, strict, missing, unexpected, errors):
+        names = {prefix + t[0] for t in self._tensors}
+        if not any(k in names for k in sd):
+            return
+        bufs = {0: self.dense.detach().clone(), 1: self.bn_stats.clone(), 2: self.bn_nbt.clone()}
+        for name, kind, off, shape, _ in self._tensors:
+            k = prefix + name
+            if k in sd:
+                v = sd.pop(k)
+                n = int(np.prod(shape)) if shape else 1
+                if tuple(v.shape) != shape:
+                    errors.append(f"size mismatch for {k}: {tuple(v.shape)} vs {shape}")
+                    continue
+                bufs[kind][off:off + n] = v.reshape(-1).to(bufs[kind].device, bufs[kind].dtype)
+            elif strict:
+                missing.append(k)
+        sd[prefix + "dense"], sd[prefix + "bn_stats"], sd[prefix + "bn_nbt"] = bufs[0], bufs[1], bufs[2]
+
+    def _l2_coef(self, device):
+        key = str(device)
+        if key not in self._coef:
+            host = torch.empty(self.dense.numel(), dtype=torch.float32)
+            L.check(L.lib().aread_model_l2_coef(self._handle, host.data_ptr()))
+            self._coef[key] = host.to(device)
+        return self._coef[key]
+
+    def _l2_partials(self, device):
+        key = str(device)
+        if key not in self._part:
+            self._part[key] = torch.empty(L.lib().aread_l2_partials(), dtype=torch.float32, device=device)
+        return self._part[key]
+
+    def get_regularization_loss(self, device=None):
+        return _RegFn.apply(self.embedding.embedding_dict.weight, self.dense, self)
+
+    # ---- one call ---------------------------------------------------------------------------------
+    def _masks_dev(self, masks, device):
+        return pack_masks(masks, self.n_domain, self._edge_count, device)
+
+    def _run(self, x, mode_id, n_seg, domain, masks_dev, want_gates, y=None, seg_weight=None, loss_out=None,
+             ws=None, plan=None, probs=None, e=None):
+        """plan + embedding + dense forward.  Returns a _CallState (buffers owned by it)."""
+        L.require_device(x, self.dense, self.embedding.embedding_dict.weight)
+        L.require(x, torch.int32, "x")
+        lib = L.lib()
+        B = x.shape[0]
+        st = _CallState()
+        st.x = x
+        st.plan = plan if plan is not None else RowPlan(x, self.domain_idx if n_seg > 1 else -1, n_seg)
+        table = self.embedding.embedding_dict.weight
+        emb = self.embedding
+        st.e = e if e is not None else torch.empty((st.plan.max_rows, self.embed_output_dim), dtype=torch.float32,
+                                                   device=x.device)
+        L.check(lib.aread_embed_fwd(L.ptr(x), B, x.shape[1], L.ptr(emb._offsets_dev(x.device)), L.ptr(table),
+                                    table.shape[0], emb.embed_dim, emb.one_hot_field_num, emb.multi_hot_field_num,
+                                    emb.seq_maxlen, emb._pool, L.ptr(st.plan.row_sample), st.plan.max_rows, L.ptr(st.e),
+                                    None, L.stream()))
+        if ws is None:
+            nbytes = lib.aread_model_workspace_bytes(self._handle, B, n_seg)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        st.ws = ws
+        st.probs = probs if probs is not None else torch.empty((self.n_heads, B), dtype=torch.float32, device=x.device)
+        gate = torch.zeros((n_seg, max(self._gate_rows, 1)), dtype=torch.float32, device=x.device) if want_gates else None
+        train = self.training
+        if train and self.dropout > 0:
+            self._drop_calls += 1
+        call = Call()
+        call.B, call.n_seg, call.mode, call.train = B, n_seg, mode_id, int(train)
+        call.update_running, call.domain = int(train), int(domain if domain is not None else 0)
+        call.drop_seed = ((self.drop_seed_base + self._drop_calls * 0x9E3779B1) if self.drop_seed is None
+                          else int(self.drop_seed)) & 0xFFFFFFFF
+        call.plan, call.masks = L.ptr(st.plan.buf), L.ptr(masks_dev)
+        call.params, call.stats, call.nbt = L.ptr(self.dense), L.ptr(self.bn_stats), L.ptr(self.bn_nbt)
+        call.ws, call.probs, call.gate_stats = L.ptr(ws), L.ptr(st.probs), L.ptr(gate)
+        call.y, call.seg_weight, call.loss_out = L.ptr(y), L.ptr(seg_weight), L.ptr(loss_out)
+        st.call = call
+        st.keep = (masks_dev, gate, y, seg_weight, loss_out)
+        L.check(lib.aread_forward(self._handle, C.byref(call), L.ptr(st.e), L.stream()))
+        return st, gate
+
+    def _record_gates(self, gate_row, d, memory_gate_value, tmp_memory_gate_value):
+        """Side outputs of aread.py:187-200,275-295 from the kernel's [gate_rows] vector."""
+        off = 0
+        for l in range(1, self.n_level):
+            for t in range(self.n_tower[l]):
+                v = gate_row[off:off + self.n_tower[l - 1]].clone()
+                off += self.n_tower[l - 1]
+                if tmp_memory_gate_value:
+                    self.tmp_tower_gate_values[l][t] = v
+                if memory_gate_value:
+                    self.domain_tower_gate_values[d][l][t].append(v)
+
+    def forward(self, x, mode="wo_mask", targets=None, memory_gate_value=False, domain_i=None, current_mask=None,
+                tmp_memory_gate_value=False):
+        """Same contract as aread.py:129-261 for 'wo_mask' ([B,1]), 'domain_with_mask' ([B]) and
+        'domain_mask_bagging' ([K_active,B]).  'with_mask' (extension) = every sample uses the mask of its
+        own domain; returns (mean over active heads, targets), both in domain order."""
+        want_gates = bool(memory_gate_value or tmp_memory_gate_value) and self._gate_rows > 0
+        table = self.embedding.embedding_dict.weight
+        if mode == "wo_mask":
+            st, gate = self._run(x, 1, 1, domain_i, None, want_gates and domain_i is not None)
+            probs = _AreadFn.apply(table, self.dense, self, x, st) if torch.is_grad_enabled() else st.probs
+            if want_gates and domain_i is not None:
+                self._record_gates(gate[0], domain_i, memory_gate_value, False)
+            return probs.mean(dim=0).unsqueeze(-1)
+        if mode in ("domain_with_mask", "domain_mask_bagging"):
+            mask = self.domain_mask[domain_i] if current_mask is None else current_mask
+            if mask is None:
+                raise ValueError("no mask for this domain (domain_mask is filled by the first regroup)")
+            act0 = np.asarray(mask[0].cpu() if isinstance(mask[0], torch.Tensor) else mask[0]).reshape(-1)
+            if not act0.any():
+                raise ValueError("mask[0] has no active level-0 tower")
+            d = 0 if domain_i is None else int(domain_i)
+            masks = [None] * self.n_domain
+            masks[d] = mask
+            last = np.asarray(mask[self.n_level - 1].cpu() if isinstance(mask[0], torch.Tensor) else mask[self.n_level - 1])
+            active = np.nonzero(last.any(axis=0))[0]
+            if active.size == 0:
+                raise RuntimeError("mask has no active last-level tower (aread.py:312-322)")
+            st, gate = self._run(x, 0, 1, d, self._masks_dev(masks, x.device), want_gates)
+            probs = _AreadFn.apply(table, self.dense, self, x, st) if torch.is_grad_enabled() else st.probs
+            if want_gates:
+                self._record_gates(gate[0], d, memory_gate_value, tmp_memory_gate_value)
+            y_stack = probs[torch.from_numpy(active).to(x.device)]
+            return y_stack if mode == "domain_mask_bagging" else y_stack.mean(dim=0)
+        if mode == "with_mask":
+            if any(m is None for m in self.domain_mask):
+                raise ValueError("with_mask needs a mask for every domain")
+            st, _ = self._run(x, 0, self.n_domain, None, self._masks_dev(self.domain_mask, x.device), False)
+            probs = _AreadFn.apply(table, self.dense, self, x, st) if torch.is_grad_enabled() else st.probs
+            kact = torch.tensor([float(np.asarray(m[self.n_level - 1].cpu() if isinstance(m[0], torch.Tensor)
+                                                  else m[self.n_level - 1]).any(axis=0).sum())
+                                 for m in self.domain_mask], device=x.device)
+            dom = x[:, self.domain_idx].long()
+            y = probs.sum(dim=0) / kact[dom]
+            order = torch.argsort(dom, stable=True)
+            return y[order], (targets[order] if targets is not None else None)
+        raise NotImplementedError(f"mode {mode!r} is not on the accelerated path (SURVEY 8a: dead in the reference)")
+
+    def debug_ws(self, st, name, cols):
+        """Test helper: view of a named workspace buffer of a finished call as [max_rows, cols] floats."""
+        off = L.lib().aread_debug_ws_offset(self._handle, st.call.B, st.call.n_seg, name.encode())
+        if off < 0:
+            raise KeyError(name)
+        f = st.ws.view(torch.float32)
+        return f[off:off + st.plan.max_rows * cols].view(st.plan.max_rows, cols)
+
+    def reset_for_mask_update(self, d=None):
+        """aread.py:383-401: (re)allocate the gate-value / candidate-mask / eval-loss bookkeeping lists."""
+        fresh = lambda: [[[] for _ in range(self.n_tower[l])] for l in range(self.n_level)] + \
+            [[[] for _ in range(self.n_tower[-1])]]
+        if d is None:
+            self.domain_tower_gate_values = [fresh() for _ in range(self.n_domain)]
+            self.gate_value_threshold = [None for _ in range(self.n_domain)]
+            self.candidate_domain_mask = [[] for _ in range(self.n_domain)]
+            self.eval_loss = [[] for _ in range(self.n_domain)]
+        else:
+            self.domain_tower_gate_values[d] = fresh()
+            self.gate_value_threshold[d] = None
+            self.candidate_domain_mask[d] = []
+            self.eval_loss[d] = []
+
+    # ---- fused training step (extension; what bench.py times) -------------------------------------------
+    def make_step_buffers(self, B, multi_domain=True, device=None):
+        device = device or self.dense.device
+        n_seg = self.n_domain if multi_domain else 1
+        lib = L.lib()
+        lay = L.PlanLayout()
+        L.check(lib.aread_plan_layout_get(B, n_seg, lay))
+        bufs = dict(
+            n_seg=n_seg, B=B,
+            ws=torch.empty(lib.aread_model_workspace_bytes(self._handle, B, n_seg), dtype=torch.uint8, device=device),
+            e=torch.empty((int(lay.max_rows), self.embed_output_dim), dtype=torch.float32, device=device),
+            de=torch.empty((int(lay.max_rows), self.embed_output_dim), dtype=torch.float32, device=device),
+            probs=torch.empty((self.n_heads, B), dtype=torch.float32, device=device),
+            loss=torch.zeros(1 + n_seg, dtype=torch.float32, device=device),
+            reg=torch.zeros(65, dtype=torch.float32, device=device),
+            total=torch.zeros(1, dtype=torch.float32, device=device),
+            gdense=torch.zeros_like(self.dense.data),
+            gtable=torch.empty_like(self.embedding.embedding_dict.weight.data),
+        )
+        return bufs
+
+    def train_step(self, x, y, bufs, masks_dev=None, domain_i=None, seg_weight=None, with_reg=True, set_grads=True,
+                   want_gates=False):
+        """forward + bagging BCE + L2 + backward to every parameter gradient, no host sync, no allocation
+        besides the row plan (run.py:668-680 without the optimizer).  y: float32 [B] on the device.
+        Returns the device scalar loss = sum_d w_d*bag_d + reg."""
+        lib = L.lib()
+        n_seg = bufs["n_seg"]
+        table = self.embedding.embedding_dict.weight
+        if masks_dev is None:
+            masks_dev = self._masks_dev(self.domain_mask, x.device)
+        st, gate = self._run(x, 0, n_seg, domain_i, masks_dev, want_gates, y=y, seg_weight=seg_weight,
+                             loss_out=bufs["loss"], ws=bufs["ws"], probs=bufs["probs"], e=bufs["e"])
+        L.check(lib.aread_backward(self._handle, C.byref(st.call), L.ptr(st.e), None, L.ptr(bufs["gdense"]),
+                                   L.ptr(bufs["de"]), L.stream()))
+        part = self._l2_partials(x.device)
+        if with_reg:
+            L.check(lib.aread_l2_table(L.ptr(table), table.numel(), self.l2_reg_embedding, 1.0, L.ptr(bufs["gtable"]),
+                                       L.ptr(part), L.stream()))
+            L.check(lib.aread_l2_finish(L.ptr(part), part.numel(), self.l2_reg_embedding, L.ptr(bufs["reg"]), 0, L.stream()))
+            L.check(lib.aread_l2_dense(L.ptr(self.dense), L.ptr(self._l2_coef(x.device)), self.dense.numel(),
+                                       L.ptr(bufs["gdense"]), L.ptr(bufs["reg"]), 1, L.stream()))
+        else:
+            bufs["gtable"].zero_()
+            bufs["reg"].zero_()
+        self.embedding.scatter_grad(x, bufs["de"], bufs["gtable"], st.plan.sample_row)
+        torch.add(bufs["loss"][:1], bufs["reg"][:1], out=bufs["total"])
+        if set_grads:
+            self.dense.grad = bufs["gdense"]
+            table.grad = bufs["gtable"]
+        self._last = (st, gate)
+        return bufs["total"]

@@ -1,0 +1,386 @@
+// dense.hip -- aread_forward / aread_backward: launch sequence of the dense path.
+// No allocation, no synchronisation, no host<->device copy: the whole sequence can be captured
+// into a hipGraph by the caller.
+#include "dense_bwd_kernels.h"
+#include "gemm.h"
+
+#define WGRAD_KCHUNK 1024
+
+struct Ctx {
+    const aread_model* m;
+    const aread_call* c;
+    WsLayout w;
+    float* ws;
+    RowsP r;
+    ModeP mp;
+    hipStream_t st;
+    int64_t rows;
+    int n_tiles;
+    uint32_t thr;
+    float keep_scale;
+    const float* params;
+};
+
+static int make_ctx(const aread_model* m, const aread_call* c, void* stream, Ctx* x) {
+    AR_CHECK_ARG(m && c, "aread: null model/call");
+    AR_CHECK_ARG(c->B > 0 && c->plan && c->params && c->ws, "aread: null plan/params/ws or B <= 0");
+    AR_CHECK_ARG(c->n_seg == 1 || c->n_seg == m->cfg.n_domain, "aread: n_seg=%d must be 1 or n_domain=%d", c->n_seg, m->cfg.n_domain);
+    AR_CHECK_ARG(c->mode == 0 || c->mode == 1, "aread: mode=%d", c->mode);
+    AR_CHECK_ARG(c->mode == 1 || c->masks, "aread: masked mode needs masks");
+    AR_CHECK_ARG(c->mode == 0 || c->n_seg == 1, "aread: wo_mask runs as one segment");
+    AR_CHECK_ARG(((uintptr_t)c->ws & 255) == 0 && ((uintptr_t)c->params & 15) == 0, "aread: ws must be 256-byte, params 16-byte aligned");
+    x->m = m; x->c = c; x->st = (hipStream_t)stream;
+    ws_layout(m, c->B, c->n_seg, &x->w);
+    x->ws = (float*)c->ws;
+    x->rows = x->w.max_rows;
+    x->n_tiles = (int)x->w.n_tiles;
+    const PlanView pv = plan_view(c->plan, c->B, c->n_seg);
+    x->r.tile_seg = pv.tile_seg; x->r.tile_valid = pv.tile_valid; x->r.row_sample = pv.row_sample;
+    x->r.seg_count = pv.seg_count; x->r.seg_start = pv.seg_start; x->r.n_tiles = x->n_tiles; x->r.n_seg = c->n_seg;
+    int32_t* ints = (int32_t*)(x->ws + x->w.kact);
+    x->mp.active = (const uint8_t*)(x->ws + x->w.active);
+    x->mp.kact = ints; x->mp.n0act = ints + MAX_SEG; x->mp.seg_dom = (int32_t*)(x->ws + x->w.seg_dom);
+    x->mp.masks = c->mode == 0 ? c->masks : nullptr;
+    x->mp.edge_count = m->edge_count; x->mp.mode = c->mode;
+    const bool drop = c->train && m->cfg.dropout > 0.f;
+    x->thr = drop ? drop_threshold(m->cfg.dropout) : 0u;
+    x->keep_scale = drop ? 1.0f / (1.0f - m->cfg.dropout) : 1.f;
+    x->params = c->params;
+    return AREAD_OK;
+}
+
+#define LAUNCH(kernel, grid, block, ...)                                       \
+    do {                                                                       \
+        hipLaunchKernelGGL(kernel, grid, block, 0, x.st, __VA_ARGS__);         \
+        AR_LAUNCH_CHECK();                                                     \
+    } while (0)
+#define TRY(expr) do { int _s = (expr); if (_s != AREAD_OK) return _s; } while (0)
+
+static const uint8_t* level_active(const Ctx& x, int level) {
+    return level >= 0 ? x.mp.active + (size_t)level * MAX_SEG * MAX_TOWER : nullptr;
+}
+
+// ---- one MLP layer forward: H = in W^T + b (statistics in the epilogue) ; finalize ; BN+ReLU+dropout ----
+static int layer_fwd(Ctx& x, const LayerL& L, const LayerWs& lw, const float* in, int level) {
+    const bool shared = L.in_gs == 0 && L.G > 1;
+    GemmP g = {};
+    g.A = in; g.lda = L.in_ld; g.a_gs = L.in_gs;
+    g.B = x.params + L.w; g.ldb = L.in_dim; g.b_gs = (int64_t)L.out_dim * L.in_dim;
+    g.C = x.ws + lw.H; g.ldc = L.ncols; g.c_gs = L.out_dim;
+    g.bias = x.params + L.b; g.bias_gs = L.out_dim;
+    g.M = (int)x.rows; g.N = L.out_dim; g.K = L.in_dim; g.G = L.G;
+    if (shared || L.G == 1) { g.N = L.ncols; g.G = 1; g.a_gs = 0; g.b_gs = 0; g.c_gs = 0; g.bias_gs = 0; }
+    g.gate_axis = 1; g.tile_seg = x.r.tile_seg; g.tile_valid = x.r.tile_valid;
+    g.active = (level >= 0 && g.G > 1) ? level_active(x, level) : nullptr; g.active_ld = MAX_TOWER;
+    if (x.c->train) { g.stat_part = x.ws + lw.part; g.stat_ld = L.ncols; }
+    TRY(launch_gemm(g, true, true, x.st));
+    BnFinP f = {};
+    f.part = x.ws + lw.part; f.mean = x.ws + lw.mean; f.rstd = x.ws + lw.rstd; f.var = x.ws + lw.var;
+    f.rmean = x.c->stats + L.rmean; f.rvar = x.c->stats + L.rvar;
+    f.ncols = L.ncols; f.h = L.out_dim; f.train = x.c->train; f.level = level; f.r = x.r; f.mp = x.mp;
+    LAUNCH(k_bn_finalize, dim3(x.c->n_seg, cdiv(L.ncols, 256)), dim3(256), f);
+    BnActP a = {};
+    a.H = x.ws + lw.H; a.Act = x.ws + lw.Act; a.mean = f.mean; a.rstd = f.rstd;
+    a.gamma = x.params + L.gamma; a.beta = x.params + L.beta;
+    a.ncols = L.ncols; a.h = L.out_dim; a.level = level; a.stack = L.stack; a.layer = L.layer; a.train = x.c->train;
+    a.seed = x.c->drop_seed; a.thr = x.thr; a.keep_scale = x.keep_scale; a.r = x.r; a.mp = x.mp;
+    LAUNCH(k_bn_act, dim3(cdiv(x.rows * (L.ncols / 4), 256)), dim3(256), a);
+    return AREAD_OK;
+}
+
+static int stack_fwd(Ctx& x, const StackL& S, const LayerWs* lw, const float* in, int level) {
+    for (int j = 0; j < S.n_layers; ++j) {
+        TRY(layer_fwd(x, S.L[j], lw[j], in, level));
+        in = x.ws + lw[j].Act;
+    }
+    return AREAD_OK;
+}
+
+static int simple_gemm(Ctx& x, const float* A, int64_t lda, bool a_kc, const float* B, int64_t ldb, bool b_kc, float* C,
+                       int64_t ldc, const float* bias, int M, int N, int K, int accumulate, int gate_axis) {
+    GemmP g = {};
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.bias = bias;
+    g.M = M; g.N = N; g.K = K; g.G = 1; g.accumulate = accumulate;
+    g.gate_axis = gate_axis; g.tile_seg = x.r.tile_seg; g.tile_valid = x.r.tile_valid;
+    return launch_gemm(g, a_kc, b_kc, x.st);
+}
+
+template <int MAXV>
+static void launch_rowwise_fwd(Ctx& x, const RowwiseP& p) {
+    hipLaunchKernelGGL((k_rowwise_fwd<MAXV>), dim3(x.n_tiles), dim3(256), 0, x.st, p);
+}
+
+extern "C" int aread_forward(const aread_model* m, const aread_call* c, const float* e_in, void* stream) {
+    Ctx x;
+    TRY(make_ctx(m, c, stream, &x));
+    AR_CHECK_ARG(e_in && c->stats, "aread_forward: null e_in/stats");
+    AR_CHECK_ARG(!(c->train && c->update_running) || c->nbt, "aread_forward: update_running needs nbt");
+    const aread_model_cfg& cfg = m->cfg;
+    const int D = m->D, E = m->E;
+    float* ws = x.ws;
+    const float* P = x.params;
+    // 1. mask tables + group embedding
+    MaskPrepP mp = {};
+    mp.masks = x.mp.masks; mp.n_seg = c->n_seg; mp.domain = c->domain; mp.mode = c->mode; mp.n_level = cfg.n_level;
+    mp.n_domain = cfg.n_domain; mp.edge_count = m->edge_count; mp.E = E;
+    for (int l = 0; l < cfg.n_level; ++l) mp.n_tower[l] = cfg.n_tower[l];
+    for (int l = 0; l <= cfg.n_level; ++l) mp.mask_off[l] = m->mask_off[l];
+    mp.group_emb = P + m->group_emb;
+    mp.active = (uint8_t*)(ws + x.w.active); mp.kact = (int32_t*)(ws + x.w.kact); mp.n0act = mp.kact + MAX_SEG;
+    mp.seg_dom = (int32_t*)(ws + x.w.seg_dom); mp.grp = ws + x.w.grp;
+    LAUNCH(k_mask_prep, dim3(1), dim3(256), mp);
+    if (c->probs) AR_HIP(hipMemsetAsync(c->probs, 0, (size_t)m->n_heads * c->B * sizeof(float), x.st));
+    // 2. row-wise trunk
+    RowwiseP rw = {};
+    rw.e = e_in; rw.cn = ws + x.w.cn; rw.lin = ws + x.w.lin; rw.xw = ws + x.w.xw; rw.q = ws + x.w.q; rw.grp = ws + x.w.grp;
+    rw.lin_w = P + m->lin_w; rw.lin_b = P + m->lin_b; rw.cn_w = P + m->cn_w; rw.cn_b = P + m->cn_b;
+    rw.D = D; rw.E = E; rw.n_cross = cfg.n_cross; rw.dom_field = cfg.domain_field; rw.rows = x.rows; rw.r = x.r;
+    if (D <= 256) launch_rowwise_fwd<1>(x, rw); else if (D <= 512) launch_rowwise_fwd<2>(x, rw); else launch_rowwise_fwd<4>(x, rw);
+    AR_LAUNCH_CHECK();
+    // 3. gate logits and the cross-network part of the heads
+    const int n_ge = cfg.n_tower[0] * cfg.n_expert;
+    TRY(simple_gemm(x, e_in, D, true, P + m->gate_w, D, true, ws + x.w.glogE, m->ld_ge, P + m->gate_b, (int)x.rows, n_ge, D, 0, 1));
+    if (m->gate_rows > 0)
+        TRY(simple_gemm(x, ws + x.w.q, 2 * E, true, P + m->tgate_w, 2 * E, true, ws + x.w.glogT, m->ld_gt, P + m->tgate_b,
+                        (int)x.rows, m->gate_rows, 2 * E, 0, 1));
+    TRY(simple_gemm(x, ws + x.w.cn, D, true, P + m->head_w, m->head_ld, true, ws + x.w.hc, m->ld_h, nullptr, (int)x.rows,
+                    m->n_heads, D, 0, 1));
+    // 4. experts
+    TRY(stack_fwd(x, m->experts, x.w.ex, e_in, -1));
+    // 5. MMoE mix -> level-0 tower inputs
+    const LayerL& EL = m->experts.L[m->experts.n_layers - 1];
+    Mix0P m0 = {};
+    m0.glog = ws + x.w.glogE; m0.ld_g = m->ld_ge; m0.X = ws + x.w.ex[m->experts.n_layers - 1].Act; m0.In0 = ws + x.w.In[0];
+    m0.n_t = cfg.n_tower[0]; m0.n_exp = cfg.n_expert; m0.h = EL.out_dim; m0.r = x.r; m0.mp = x.mp;
+    LAUNCH(k_mix0, dim3(cdiv(x.rows * m0.n_t * (m0.h / 4), 256)), dim3(256), m0);
+    // 6. tower pyramid
+    const bool want_gates = c->gate_stats != nullptr && m->gate_rows > 0;
+    for (int l = 0; l < cfg.n_level; ++l) {
+        const StackL& S = m->towers[l];
+        if (l > 0) {
+            const StackL& Sp = m->towers[l - 1];
+            MixLP ml = {};
+            ml.glog = ws + x.w.glogT; ml.ld_g = m->ld_gt; ml.goff = m->gate_off[l];
+            ml.prev = ws + x.w.tw[l - 1][Sp.n_layers - 1].Act; ml.In = ws + x.w.In[l];
+            ml.n_src = cfg.n_tower[l - 1]; ml.n_t = cfg.n_tower[l]; ml.w = S.L[0].in_dim; ml.level = l; ml.mask_off = m->mask_off[l];
+            ml.gate_part = want_gates ? ws + x.w.gate_part : nullptr; ml.r = x.r; ml.mp = x.mp;
+            LAUNCH(k_mixl, dim3(x.n_tiles), dim3(256), ml);
+        }
+        TRY(stack_fwd(x, S, x.w.tw[l], ws + x.w.In[l], l));
+    }
+    if (want_gates) LAUNCH(k_gate_stats, dim3(c->n_seg), dim3(256), ws + x.w.gate_part, m->ld_gt, m->gate_rows, c->gate_stats, x.r);
+    // 7. heads + fused bagging loss
+    const int LL = cfg.n_level - 1;
+    HeadsP hp = {};
+    hp.hc = ws + x.w.hc; hp.lin = ws + x.w.lin; hp.act = ws + x.w.tw[LL][m->towers[LL].n_layers - 1].Act;
+    hp.head_w = P + m->head_w; hp.head_ld = m->head_ld; hp.D = D; hp.h = m->h_last; hp.n_heads = m->n_heads; hp.ld_h = m->ld_h;
+    hp.z = ws + x.w.z; hp.prob = ws + x.w.prob; hp.dz = ws + x.w.dz; hp.probs_out = c->probs; hp.B = c->B;
+    hp.y = c->y; hp.seg_weight = c->seg_weight; hp.dprobs = nullptr;
+    hp.loss_part = (c->y && c->loss_out) ? ws + x.w.loss_part : nullptr; hp.level = LL; hp.r = x.r; hp.mp = x.mp;
+    LAUNCH(k_heads_fwd, dim3(x.n_tiles), dim3(256), hp);
+    if (hp.loss_part) LAUNCH(k_loss_finish, dim3(1), dim3(64), ws + x.w.loss_part, c->seg_weight, c->loss_out, x.r);
+    // 8. running statistics, in domain order
+    if (c->train && c->update_running) {
+        auto run = [&](const LayerL& L, const LayerWs& lw, int level) -> int {
+            BnRunP p = {};
+            p.mean = ws + lw.mean; p.var = ws + lw.var; p.rmean = c->stats + L.rmean; p.rvar = c->stats + L.rvar;
+            p.nbt = c->nbt + L.nbt0; p.ncols = L.ncols; p.h = L.out_dim; p.level = level; p.r = x.r; p.mp = x.mp;
+            LAUNCH(k_bn_running, dim3(cdiv(L.ncols, 256)), dim3(256), p);
+            return AREAD_OK;
+        };
+        for (int j = 0; j < m->experts.n_layers; ++j) TRY(run(m->experts.L[j], x.w.ex[j], -1));
+        for (int l = 0; l < cfg.n_level; ++l)
+            for (int j = 0; j < m->towers[l].n_layers; ++j) TRY(run(m->towers[l].L[j], x.w.tw[l][j], l));
+    }
+    return AREAD_OK;
+}
+
+// ================================================================================================
+// backward
+// ================================================================================================
+static int wgrad(Ctx& x, const float* dY, int64_t ld_dy, int64_t dy_gs, const float* X, int64_t ldx, int64_t x_gs, int G,
+                 int M, int N, float* out, int64_t ldo, int64_t o_gs, const uint8_t* active) {
+    const int ksplit = cdiv(x.rows, WGRAD_KCHUNK);
+    GemmP g = {};
+    g.A = dY; g.lda = ld_dy; g.a_gs = dy_gs;
+    g.B = X; g.ldb = ldx; g.b_gs = x_gs;
+    g.C = x.ws + x.w.slab; g.ldc = N; g.c_gs = (int64_t)M * N; g.c_ks = (int64_t)G * M * N;
+    g.M = M; g.N = N; g.K = (int)x.rows; g.G = G;
+    g.k_split = ksplit; g.k_chunk = WGRAD_KCHUNK;
+    g.gate_axis = 2; g.tile_seg = x.r.tile_seg; g.tile_valid = x.r.tile_valid; g.active = active; g.active_ld = MAX_TOWER;
+    TRY(launch_gemm(g, false, false, x.st));
+    LAUNCH(k_splitk_reduce, dim3(cdiv((int64_t)G * M * N, 256)), dim3(256), x.ws + x.w.slab, ksplit, G, M, N, out, ldo, o_gs, 0);
+    return AREAD_OK;
+}
+
+// one MLP layer backward.  d = dL/dAct on entry (in lw.dAct); on exit it holds dL/dH.
+static int layer_bwd(Ctx& x, const LayerL& L, const LayerWs& lw, const float* in, float* d_in, int accumulate_d_in,
+                     float* grads, int level) {
+    float* ws = x.ws;
+    float* d = ws + lw.dAct;
+    ActBwdP a = {};
+    a.d = d; a.H = ws + lw.H; a.mean = ws + lw.mean; a.rstd = ws + lw.rstd;
+    a.gamma = x.params + L.gamma; a.beta = x.params + L.beta; a.bpart = ws + lw.bpart;
+    a.ncols = L.ncols; a.h = L.out_dim; a.level = level; a.stack = L.stack; a.layer = L.layer; a.train = x.c->train;
+    a.seed = x.c->drop_seed; a.thr = x.thr; a.keep_scale = x.keep_scale; a.r = x.r; a.mp = x.mp;
+    LAUNCH(k_act_bwd, dim3(x.n_tiles, cdiv(L.ncols, 64)), dim3(256), a);
+    BnBwdFinP f = {};
+    f.bpart = ws + lw.bpart; f.s12 = ws + lw.s12; f.dgamma = grads + L.gamma; f.dbeta = grads + L.beta;
+    f.ncols = L.ncols; f.h = L.out_dim; f.level = level; f.r = x.r; f.mp = x.mp;
+    LAUNCH(k_bn_bwd_finalize, dim3(cdiv(L.ncols, 256)), dim3(256), f);
+    BnBwdApplyP b = {};
+    b.d = d; b.H = ws + lw.H; b.mean = ws + lw.mean; b.rstd = ws + lw.rstd; b.gamma = x.params + L.gamma; b.s12 = ws + lw.s12;
+    b.cpart = ws + lw.cpart; b.ncols = L.ncols; b.h = L.out_dim; b.level = level; b.r = x.r; b.mp = x.mp;
+    LAUNCH(k_bn_bwd_apply, dim3(x.n_tiles, cdiv(L.ncols, 64)), dim3(256), b);
+    LAUNCH(k_reduce_tiles, dim3(cdiv(L.ncols, 256)), dim3(256), ws + lw.cpart, (int64_t)L.ncols, L.ncols, grads + L.b, L.ncols,
+           (int64_t)0, 0, x.r);
+    const bool shared = L.in_gs == 0 && L.G > 1;
+    const uint8_t* act = (level >= 0 && L.G > 1) ? level_active(x, level) : nullptr;
+    // dgrad: d_in = dH W
+    if (d_in) {
+        GemmP g = {};
+        g.A = d; g.lda = L.ncols; g.a_gs = L.out_dim;
+        g.B = x.params + L.w; g.ldb = L.in_dim; g.b_gs = (int64_t)L.out_dim * L.in_dim;
+        g.C = d_in; g.ldc = L.in_ld; g.c_gs = L.in_gs;
+        g.M = (int)x.rows; g.N = L.in_dim; g.K = L.out_dim; g.G = L.G; g.accumulate = accumulate_d_in;
+        if (shared || L.G == 1) { g.K = L.ncols; g.G = 1; g.a_gs = 0; g.b_gs = 0; g.c_gs = 0; }
+        g.gate_axis = 1; g.tile_seg = x.r.tile_seg; g.tile_valid = x.r.tile_valid;
+        TRY(launch_gemm(g, true, false, x.st));   // inactive towers contribute dH = 0
+    }
+    // wgrad: dW = dH^T in
+    if (shared) TRY(wgrad(x, d, L.ncols, 0, in, L.in_ld, 0, 1, L.ncols, L.in_dim, grads + L.w, L.in_dim, 0, nullptr));
+    else TRY(wgrad(x, d, L.ncols, L.out_dim, in, L.in_ld, L.in_gs, L.G, L.out_dim, L.in_dim, grads + L.w, L.in_dim,
+                   (int64_t)L.out_dim * L.in_dim, act));
+    return AREAD_OK;
+}
+
+template <int NC, int MAXV>
+static void launch_rowwise_bwd2(Ctx& x, const RowwiseBwdP& p) {
+    hipLaunchKernelGGL((k_rowwise_bwd<NC, MAXV>), dim3(x.n_tiles), dim3(256), 0, x.st, p);
+}
+template <int MAXV>
+static void launch_rowwise_bwd(Ctx& x, const RowwiseBwdP& p) {
+    switch (p.n_cross) {
+        case 0: launch_rowwise_bwd2<0, MAXV>(x, p); break;
+        case 1: launch_rowwise_bwd2<1, MAXV>(x, p); break;
+        case 2: launch_rowwise_bwd2<2, MAXV>(x, p); break;
+        case 3: launch_rowwise_bwd2<3, MAXV>(x, p); break;
+        default: launch_rowwise_bwd2<4, MAXV>(x, p); break;
+    }
+}
+
+extern "C" int aread_backward(const aread_model* m, const aread_call* c, const float* e_in, const float* dprobs,
+                              float* grads, float* de_out, void* stream) {
+    Ctx x;
+    TRY(make_ctx(m, c, stream, &x));
+    AR_CHECK_ARG(e_in && grads && de_out, "aread_backward: null e_in/grads/de_out");
+    AR_CHECK_ARG(dprobs || c->y, "aread_backward: need dprobs or labels");
+    AR_CHECK_ARG(((uintptr_t)grads & 15) == 0 && ((uintptr_t)de_out & 15) == 0, "aread_backward: alignment");
+    const aread_model_cfg& cfg = m->cfg;
+    const int D = m->D, E = m->E, LL = cfg.n_level - 1;
+    float* ws = x.ws;
+    const float* P = x.params;
+    AR_HIP(hipMemsetAsync(grads, 0, (size_t)m->n_params * sizeof(float), x.st));
+    // 1. dz
+    HeadsP hp = {};
+    hp.prob = ws + x.w.prob; hp.dz = ws + x.w.dz; hp.n_heads = m->n_heads; hp.ld_h = m->ld_h; hp.B = c->B;
+    hp.y = c->y; hp.seg_weight = c->seg_weight; hp.dprobs = dprobs; hp.level = LL; hp.r = x.r; hp.mp = x.mp;
+    LAUNCH(k_heads_dz, dim3(x.n_tiles), dim3(256), hp);
+    // 2. heads backward
+    const LayerWs& last = x.w.tw[LL][m->towers[LL].n_layers - 1];
+    HeadsBwdP hb = {};
+    hb.dz = ws + x.w.dz; hb.act = ws + last.Act; hb.head_w = P + m->head_w; hb.head_ld = m->head_ld; hb.D = D; hb.h = m->h_last;
+    hb.n_heads = m->n_heads; hb.ld_h = m->ld_h; hb.dact = ws + last.dAct; hb.dlin = ws + x.w.dlin;
+    hb.part = ws + x.w.misc_part; hb.ldp = 1024; hb.r = x.r;
+    AR_CHECK_ARG(m->n_heads * m->h_last <= 1024, "aread_backward: n_heads*h_last too large");
+    LAUNCH(k_heads_bwd, dim3(x.n_tiles), dim3(256), hb);
+    LAUNCH(k_reduce_tiles, dim3(cdiv(m->n_heads * m->h_last, 256)), dim3(256), ws + x.w.misc_part, (int64_t)1024,
+           m->n_heads * m->h_last, grads + m->head_w + D, m->h_last, (int64_t)m->head_ld, 0, x.r);
+    // dcn = dz V[:, :D]   and   dV[:, :D] = dz^T cn
+    TRY(simple_gemm(x, ws + x.w.dz, m->ld_h, true, P + m->head_w, m->head_ld, false, ws + x.w.dcn, D, nullptr, (int)x.rows, D,
+                    m->n_heads, 0, 1));
+    TRY(wgrad(x, ws + x.w.dz, m->ld_h, 0, ws + x.w.cn, D, 0, 1, m->n_heads, D, grads + m->head_w, m->head_ld, 0, nullptr));
+    // 3. tower pyramid, top down
+    for (int l = LL; l >= 0; --l) {
+        const StackL& S = m->towers[l];
+        for (int j = S.n_layers - 1; j >= 0; --j) {
+            const float* in = j == 0 ? ws + x.w.In[l] : ws + x.w.tw[l][j - 1].Act;
+            float* d_in = j == 0 ? ws + x.w.dIn[l] : ws + x.w.tw[l][j - 1].dAct;
+            TRY(layer_bwd(x, S.L[j], x.w.tw[l][j], in, d_in, 0, grads, l));
+        }
+        if (l > 0) {
+            const StackL& Sp = m->towers[l - 1];
+            MixLBwdP mb = {};
+            mb.glog = ws + x.w.glogT; mb.dglog = ws + x.w.dglogT; mb.ld_g = m->ld_gt; mb.goff = m->gate_off[l];
+            mb.prev = ws + x.w.tw[l - 1][Sp.n_layers - 1].Act; mb.dIn = ws + x.w.dIn[l];
+            mb.dprev = ws + x.w.tw[l - 1][Sp.n_layers - 1].dAct;
+            mb.n_src = cfg.n_tower[l - 1]; mb.n_t = cfg.n_tower[l]; mb.w = S.L[0].in_dim; mb.level = l; mb.mask_off = m->mask_off[l];
+            mb.r = x.r; mb.mp = x.mp;
+            LAUNCH(k_mixl_bwd, dim3(x.n_tiles), dim3(256), mb);
+        }
+    }
+    // 4. MMoE mix backward
+    const int nle = m->experts.n_layers;
+    const LayerL& EL = m->experts.L[nle - 1];
+    Mix0BwdP m0 = {};
+    m0.glog = ws + x.w.glogE; m0.dglog = ws + x.w.dglogE; m0.ld_g = m->ld_ge; m0.X = ws + x.w.ex[nle - 1].Act;
+    m0.dU = ws + x.w.dIn[0]; m0.dX = ws + x.w.ex[nle - 1].dAct; m0.n_t = cfg.n_tower[0]; m0.n_exp = cfg.n_expert; m0.h = EL.out_dim;
+    m0.r = x.r; m0.mp = x.mp;
+    LAUNCH(k_mix0_bwd, dim3(x.n_tiles), dim3(256), m0);
+    // 5. experts; the first layer writes de_out
+    for (int j = nle - 1; j >= 0; --j) {
+        const float* in = j == 0 ? e_in : ws + x.w.ex[j - 1].Act;
+        float* d_in = j == 0 ? de_out : ws + x.w.ex[j - 1].dAct;
+        TRY(layer_bwd(x, m->experts.L[j], x.w.ex[j], in, d_in, 0, grads, -1));
+    }
+    // 6. gates
+    const int n_ge = cfg.n_tower[0] * cfg.n_expert;
+    TRY(simple_gemm(x, ws + x.w.dglogE, m->ld_ge, true, P + m->gate_w, D, false, de_out, D, nullptr, (int)x.rows, D, n_ge, 1, 1));
+    TRY(wgrad(x, ws + x.w.dglogE, m->ld_ge, 0, e_in, D, 0, 1, n_ge, D, grads + m->gate_w, D, 0, nullptr));
+    LAUNCH(k_colsum, dim3(x.n_tiles), dim3(256), ws + x.w.dglogE, (int64_t)m->ld_ge, n_ge, ws + x.w.misc_part, (int64_t)1024, x.r);
+    LAUNCH(k_reduce_tiles, dim3(cdiv(n_ge, 256)), dim3(256), ws + x.w.misc_part, (int64_t)1024, n_ge, grads + m->gate_b, n_ge,
+           (int64_t)0, 0, x.r);
+    if (m->gate_rows > 0) {
+        TRY(simple_gemm(x, ws + x.w.dglogT, m->ld_gt, true, P + m->tgate_w, 2 * E, false, ws + x.w.dq, 2 * E, nullptr, (int)x.rows,
+                        2 * E, m->gate_rows, 0, 1));
+        TRY(wgrad(x, ws + x.w.dglogT, m->ld_gt, 0, ws + x.w.q, 2 * E, 0, 1, m->gate_rows, 2 * E, grads + m->tgate_w, 2 * E, 0, nullptr));
+        AR_CHECK_ARG(m->gate_rows <= 1024, "aread_backward: too many gate rows");
+        LAUNCH(k_colsum, dim3(x.n_tiles), dim3(256), ws + x.w.dglogT, (int64_t)m->ld_gt, m->gate_rows, ws + x.w.misc_part,
+               (int64_t)1024, x.r);
+        LAUNCH(k_reduce_tiles, dim3(cdiv(m->gate_rows, 256)), dim3(256), ws + x.w.misc_part, (int64_t)1024, m->gate_rows,
+               grads + m->tgate_b, m->gate_rows, (int64_t)0, 0, x.r);
+    } else {
+        AR_HIP(hipMemsetAsync(ws + x.w.dq, 0, (size_t)x.rows * 2 * E * sizeof(float), x.st));
+    }
+    // 7. row-wise trunk backward (adds into de_out)
+    RowwiseBwdP rb = {};
+    rb.e = e_in; rb.xw = ws + x.w.xw; rb.dcn = ws + x.w.dcn; rb.dlin = ws + x.w.dlin; rb.dq = ws + x.w.dq;
+    rb.lin_w = P + m->lin_w; rb.cn_w = P + m->cn_w; rb.cn_b = P + m->cn_b;
+    rb.de = de_out; rb.part = ws + x.w.rw_part; rb.part_ld = (int64_t)(2 * cfg.n_cross + 1) * D + 4; rb.dgrp_part = ws + x.w.dgrp_part;
+    rb.D = D; rb.E = E; rb.n_cross = cfg.n_cross; rb.dom_field = cfg.domain_field; rb.rows = x.rows; rb.r = x.r;
+    if (D <= 256) launch_rowwise_bwd<1>(x, rb); else if (D <= 512) launch_rowwise_bwd<2>(x, rb); else launch_rowwise_bwd<4>(x, rb);
+    AR_LAUNCH_CHECK();
+    const float* rp = ws + x.w.rw_part;
+    if (cfg.n_cross > 0) {
+        LAUNCH(k_reduce_tiles, dim3(cdiv(cfg.n_cross * D, 256)), dim3(256), rp, rb.part_ld, cfg.n_cross * D, grads + m->cn_w,
+               cfg.n_cross * D, (int64_t)0, 0, x.r);
+        LAUNCH(k_reduce_tiles, dim3(cdiv(cfg.n_cross * D, 256)), dim3(256), rp + (int64_t)cfg.n_cross * D, rb.part_ld, cfg.n_cross * D,
+               grads + m->cn_b, cfg.n_cross * D, (int64_t)0, 0, x.r);
+    }
+    LAUNCH(k_reduce_tiles, dim3(cdiv(D + 1, 256)), dim3(256), rp + (int64_t)2 * cfg.n_cross * D, rb.part_ld, D, grads + m->lin_w, D,
+           (int64_t)0, 0, x.r);
+    LAUNCH(k_reduce_tiles, dim3(1), dim3(256), rp + (int64_t)(2 * cfg.n_cross + 1) * D, rb.part_ld, 1, grads + m->lin_b, 1,
+           (int64_t)0, 0, x.r);
+    // 8. group embedding
+    LAUNCH(k_grp_bwd, dim3(1), dim3(256), ws + x.w.dgrp_part, grads + m->group_emb, cfg.n_tower[0], E, x.r, x.mp);
+    return AREAD_OK;
+}
+
+extern "C" int aread_l2_dense(const float* params, const float* coef, int64_t n, float* grads, float* loss_out,
+                              int accumulate, void* stream) {
+    AR_CHECK_ARG(params && coef && loss_out && n > 0, "aread_l2_dense: bad arguments");
+    // the partial sums live at the tail of loss_out's caller-provided scratch: loss_out[1..64]
+    hipLaunchKernelGGL(k_l2_dense, dim3(64), dim3(256), 0, (hipStream_t)stream, params, coef, n, grads, loss_out + 1);
+    AR_LAUNCH_CHECK();
+    return aread_l2_finish(loss_out + 1, 64, 1.0f, loss_out, accumulate, stream);
+}

@@ -1,0 +1,478 @@
+// dense_kernels.h -- the non-GEMM kernels of the dense path.  Everything here is row-local or a
+// per-(segment, column) reduction: HBM/L2-bandwidth or latency bound, fp32 throughout.
+//
+// Row layout: rows follow the row plan (segments = domains, padded to 64-row tiles).  A tile is
+// entirely inside one segment, so the domain mask, the BatchNorm statistics and the "is this tower
+// active for this domain" predicate are wave-uniform: there is no host-side branching anywhere.
+#pragma once
+#include "common.h"
+#include "model.h"
+
+#define BN_EPS 1e-5f
+#define BN_MOMENTUM 0.1f
+#define GATE_EPS 1e-8f
+
+struct RowsP {                       // the parts of the row plan a kernel needs
+    const int32_t* tile_seg;
+    const int32_t* tile_valid;
+    const int32_t* row_sample;
+    const int32_t* seg_count;
+    const int32_t* seg_start;
+    int n_tiles, n_seg;
+};
+
+struct ModeP {                       // per-call mask tables (built by k_mask_prep)
+    const uint8_t* active;           // [n_level][MAX_SEG][MAX_TOWER]
+    const int32_t* kact;             // [MAX_SEG] active heads
+    const int32_t* n0act;            // [MAX_SEG] active level-0 towers
+    const int32_t* seg_dom;          // [MAX_SEG] domain of a segment
+    const uint8_t* masks;            // [n_domain][edge_count] (nullable in wo_mask)
+    int edge_count, mode;
+};
+
+__device__ __forceinline__ const uint8_t* active_level(const ModeP& mp, int l) {
+    return mp.active + (size_t)l * MAX_SEG * MAX_TOWER;
+}
+
+// ------------------------------------------------------------------------------------------------
+// mask tables + group embedding  (aread.py:225-230,266-268)
+// ------------------------------------------------------------------------------------------------
+struct MaskPrepP {
+    const uint8_t* masks; int n_seg, domain, mode, n_level, n_domain, edge_count, E;
+    int n_tower[AREAD_MAX_LEVEL]; int mask_off[AREAD_MAX_LEVEL + 1];
+    const float* group_emb;
+    uint8_t* active; int32_t* kact; int32_t* n0act; int32_t* seg_dom; float* grp;
+};
+
+__global__ __launch_bounds__(256) void k_mask_prep(const MaskPrepP p) {
+    const int tid = threadIdx.x;
+    for (int i = tid; i < AREAD_MAX_LEVEL * MAX_SEG * MAX_TOWER; i += 256) p.active[i] = 0;
+    __syncthreads();
+    for (int s = tid; s < MAX_SEG; s += 256) {
+        int dom = p.n_seg == 1 ? p.domain : s;
+        if (dom < 0) dom = 0;
+        if (dom >= p.n_domain) dom = p.n_domain - 1;
+        p.seg_dom[s] = dom;
+        int k = 0, n0 = 0;
+        if (s < p.n_seg) {
+            const uint8_t* mk = p.masks ? p.masks + (size_t)dom * p.edge_count : nullptr;
+            for (int l = 0; l < p.n_level; ++l) {
+                const int n_src = l == 0 ? 1 : p.n_tower[l - 1];
+                for (int t = 0; t < p.n_tower[l]; ++t) {
+                    int a = 0;
+                    if (p.mode == 1) a = 1;
+                    else
+                        for (int src = 0; src < n_src; ++src) a |= mk[p.mask_off[l] + src * p.n_tower[l] + t] ? 1 : 0;
+                    p.active[((size_t)l * MAX_SEG + s) * MAX_TOWER + t] = (uint8_t)a;
+                    if (l == 0) n0 += a;
+                    if (l == p.n_level - 1) k += a;
+                }
+            }
+        }
+        p.kact[s] = k;
+        p.n0act[s] = n0;
+    }
+    __syncthreads();
+    // group embedding of each segment: mean of the rows of the active level-0 towers (0 in wo_mask)
+    for (int i = tid; i < p.n_seg * p.E; i += 256) {
+        const int s = i / p.E, c = i - s * p.E;
+        float acc = 0.f;
+        if (p.mode == 0) {
+            for (int t = 0; t < p.n_tower[0]; ++t)
+                if (p.active[(size_t)s * MAX_TOWER + t]) acc += p.group_emb[t * p.E + c];
+            const int n0 = p.n0act[s];
+            if (n0 > 1) acc = acc / (float)n0;
+        }
+        p.grp[i] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// row-wise trunk: linear term, cross network, gate input  (layer.py:115-126, 529-537; aread.py:132,230)
+// one wave per row; lane i owns float4 chunks i, i+64, ...
+// ------------------------------------------------------------------------------------------------
+struct RowwiseP {
+    const float* e; float* cn; float* lin; float* xw; float* q; const float* grp;
+    const float* lin_w; const float* lin_b; const float* cn_w; const float* cn_b;
+    int D, E, n_cross, dom_field; int64_t rows;
+    RowsP r;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) {
+    return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+}
+
+template <int RW_MAXV>
+__global__ __launch_bounds__(256) void k_rowwise_fwd(const RowwiseP p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tile = blockIdx.x;
+    const int seg = p.r.tile_seg[tile];
+    if (seg < 0) return;
+    const int nvalid = p.r.tile_valid[tile];
+    const int d4 = p.D >> 2;
+    for (int rr = wave; rr < TILE_M; rr += 4) {
+        const int64_t row = (int64_t)tile * TILE_M + rr;
+        const bool valid = rr < nvalid;
+        float4 e[RW_MAXV], c[RW_MAXV];
+        const float4* e4 = (const float4*)(p.e + row * p.D);
+#pragma unroll
+        for (int v = 0; v < RW_MAXV; ++v) {
+            const int ch = lane + 64 * v;
+            e[v] = (ch < d4 && valid) ? e4[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
+            c[v] = e[v];
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int v = 0; v < RW_MAXV; ++v) {
+            const int ch = lane + 64 * v;
+            if (ch < d4) s += dot4(e[v], ((const float4*)p.lin_w)[ch]);
+        }
+        s = wave_sum(s) + p.lin_b[0];
+        if (lane == 0) p.lin[row] = valid ? s : 0.f;
+        for (int i = 0; i < p.n_cross; ++i) {
+            const float4* w4 = (const float4*)(p.cn_w + (int64_t)i * p.D);
+            const float4* b4 = (const float4*)(p.cn_b + (int64_t)i * p.D);
+            float xw = 0.f;
+#pragma unroll
+            for (int v = 0; v < RW_MAXV; ++v) {
+                const int ch = lane + 64 * v;
+                if (ch < d4) xw += dot4(c[v], w4[ch]);
+            }
+            xw = wave_sum(xw);
+            if (lane == 0) p.xw[(int64_t)i * p.rows + row] = xw;
+#pragma unroll
+            for (int v = 0; v < RW_MAXV; ++v) {
+                const int ch = lane + 64 * v;
+                if (ch < d4) {
+                    const float4 b = b4[ch];
+                    c[v].x = e[v].x * xw + b.x + c[v].x;
+                    c[v].y = e[v].y * xw + b.y + c[v].y;
+                    c[v].z = e[v].z * xw + b.z + c[v].z;
+                    c[v].w = e[v].w * xw + b.w + c[v].w;
+                }
+            }
+        }
+        float4* cn4 = (float4*)(p.cn + row * p.D);
+#pragma unroll
+        for (int v = 0; v < RW_MAXV; ++v) {
+            const int ch = lane + 64 * v;
+            if (ch < d4) cn4[ch] = valid ? c[v] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        // gate input q = [domain embedding, group embedding]
+        const int E = p.E;
+        for (int cidx = lane; cidx < 2 * E; cidx += 64) {
+            float v = 0.f;
+            if (valid) v = cidx < E ? p.e[row * p.D + p.dom_field * E + cidx] : p.grp[seg * E + (cidx - E)];
+            p.q[row * 2 * E + cidx] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm statistics: combine the per-tile (mean, M2) partials of a segment (Chan), fixed order.
+// grid (n_seg, ceil(ncols/256)).
+// ------------------------------------------------------------------------------------------------
+struct BnFinP {
+    const float* part; float* mean; float* rstd; float* var; const float* rmean; const float* rvar;
+    int ncols, h, train, level;        // level < 0: experts (always active)
+    RowsP r; ModeP mp;
+};
+
+__global__ __launch_bounds__(256) void k_bn_finalize(const BnFinP p) {
+    const int seg = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= p.ncols) return;
+    const int cnt = p.r.seg_count[seg];
+    float mean = 0.f, rstd = 1.f, var = 0.f;
+    bool act = cnt > 0;
+    if (act && p.level >= 0) act = active_level(p.mp, p.level)[seg * MAX_TOWER + c / p.h] != 0;
+    if (act && cnt > 1) {
+        if (p.train) {
+            const int t0 = p.r.seg_start[seg] / TILE_M, nt = (cnt + TILE_M - 1) / TILE_M;
+            float n = 0.f, m2 = 0.f;
+            for (int t = 0; t < nt; ++t) {
+                const float* pp = p.part + ((int64_t)(t0 + t) * p.ncols + c) * 2;
+                const float nb = (float)p.r.tile_valid[t0 + t], mb = pp[0], m2b = pp[1];
+                const float tot = n + nb, delta = mb - mean;
+                mean += delta * (nb / tot);
+                m2 += m2b + delta * delta * (n * nb / tot);
+                n = tot;
+            }
+            var = m2 / (float)cnt;
+            rstd = 1.0f / sqrtf(var + BN_EPS);
+        } else {
+            mean = p.rmean[c];
+            var = p.rvar[c];
+            rstd = 1.0f / sqrtf(var + BN_EPS);
+        }
+    }
+    const int64_t o = (int64_t)seg * p.ncols + c;
+    p.mean[o] = mean; p.rstd[o] = rstd; p.var[o] = var;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BN apply + ReLU + dropout: H -> Act   (layer.py:209-229).  One thread per float4.
+// ------------------------------------------------------------------------------------------------
+struct BnActP {
+    const float* H; float* Act; const float* mean; const float* rstd; const float* gamma; const float* beta;
+    int ncols, h, level, stack, layer, train;
+    uint32_t seed, thr; float keep_scale;
+    RowsP r; ModeP mp;
+};
+
+__global__ __launch_bounds__(256) void k_bn_act(const BnActP p) {
+    const int c4n = p.ncols >> 2;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row = idx / c4n;
+    const int c = (int)(idx - row * c4n) * 4;
+    const int tile = (int)(row / TILE_M);
+    if (tile >= p.r.n_tiles) return;
+    const int seg = p.r.tile_seg[tile];
+    if (seg < 0) return;
+    const int rr = (int)(row - (int64_t)tile * TILE_M);
+    const int g = c / p.h;
+    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool act = rr < p.r.tile_valid[tile];
+    if (act && p.level >= 0) act = active_level(p.mp, p.level)[seg * MAX_TOWER + g] != 0;
+    if (act) {
+        const float4 hv = *(const float4*)(p.H + row * p.ncols + c);
+        float y[4] = {hv.x, hv.y, hv.z, hv.w};
+        if (p.r.seg_count[seg] > 1) {
+            const int64_t so = (int64_t)seg * p.ncols + c;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) y[i] = (y[i] - p.mean[so + i]) * p.rstd[so + i] * p.gamma[c + i] + p.beta[c + i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[i] = y[i] > 0.f ? y[i] : 0.f;
+        if (p.train && p.thr) {
+            const uint32_t key = drop_row_key(p.seed, (uint32_t)p.r.row_sample[row]);
+            const uint32_t site = (uint32_t)((p.stack * 8 + p.layer) * 64 + g);
+            const int cg = c - g * p.h;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) y[i] = drop_keep(key, site, (uint32_t)(cg + i), p.thr) ? y[i] * p.keep_scale : 0.f;
+        }
+        out = make_float4(y[0], y[1], y[2], y[3]);
+    }
+    *(float4*)(p.Act + row * p.ncols + c) = out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// MMoE mix (aread.py:152-153): In0[row][t][:] = sum_k softmax(glogE[row][t][:])_k * X[row][k][:]
+// ------------------------------------------------------------------------------------------------
+struct Mix0P {
+    const float* glog; int ld_g; const float* X; float* In0;
+    int n_t, n_exp, h;      // X: [rows][n_exp*h], In0: [rows][n_t*h]
+    RowsP r; ModeP mp;
+};
+
+__global__ __launch_bounds__(256) void k_mix0(const Mix0P p) {
+    const int h4 = p.h >> 2, per_row = p.n_t * h4;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row = idx / per_row;
+    const int rem = (int)(idx - row * per_row);
+    const int t = rem / h4, c = (rem - t * h4) * 4;
+    const int tile = (int)(row / TILE_M);
+    if (tile >= p.r.n_tiles) return;
+    const int seg = p.r.tile_seg[tile];
+    if (seg < 0) return;
+    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool act = (row - (int64_t)tile * TILE_M) < p.r.tile_valid[tile] && active_level(p.mp, 0)[seg * MAX_TOWER + t];
+    if (act) {
+        const float* gl = p.glog + row * p.ld_g + t * p.n_exp;
+        float mx = gl[0];
+        for (int k = 1; k < p.n_exp; ++k) mx = fmaxf(mx, gl[k]);
+        float den = 0.f;
+        for (int k = 0; k < p.n_exp; ++k) den += __expf(gl[k] - mx);
+        for (int k = 0; k < p.n_exp; ++k) {
+            const float w = __expf(gl[k] - mx) / den;
+            const float4 x = *(const float4*)(p.X + row * (p.n_exp * p.h) + k * p.h + c);
+            out.x += w * x.x; out.y += w * x.y; out.z += w * x.z; out.w += w * x.w;
+        }
+    }
+    *(float4*)(p.In0 + row * (p.n_t * p.h) + t * p.h + c) = out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// masked gate mix of level l >= 1 (aread.py:282-295): one thread per (row, tower t).
+// Also emits per-tile sums of gate*mask for the HEMP gate statistics.
+// ------------------------------------------------------------------------------------------------
+struct MixLP {
+    const float* glog; int ld_g, goff;        // gate logits of this level start at column goff
+    const float* prev; float* In;             // prev: [rows][n_src*w]  In: [rows][n_t*w]
+    int n_src, n_t, w, level, mask_off;
+    float* gate_part;                          // nullable: [n_tiles][ld_g] per-tile sums of gate*mask
+    RowsP r; ModeP mp;
+};
+
+__device__ __forceinline__ void gate_weights(const float* gl, int n_src, const uint8_t* mk, int n_t, int t, int mode,
+                                             float* a, float* am, float* ah, float* S) {
+    float mx = gl[0];
+    for (int s = 1; s < n_src; ++s) mx = fmaxf(mx, gl[s]);
+    float den = 0.f;
+    for (int s = 0; s < n_src; ++s) { a[s] = __expf(gl[s] - mx); den += a[s]; }
+    float sum = 0.f;
+    for (int s = 0; s < n_src; ++s) {
+        a[s] = a[s] / den;
+        am[s] = (mode == 1 || mk[s * n_t + t]) ? a[s] : 0.f;
+        sum += am[s];
+    }
+    if (mode == 1) { for (int s = 0; s < n_src; ++s) ah[s] = a[s]; *S = 1.f; }
+    else { *S = sum + GATE_EPS; for (int s = 0; s < n_src; ++s) ah[s] = am[s] / *S; }
+}
+
+__global__ __launch_bounds__(256) void k_mixl(const MixLP p) {
+    // block = one 64-row tile; threads loop over (row, t) pairs
+    __shared__ float s_gate[TILE_M][MAX_TOWER * MAX_TOWER / 2 + 1];
+    const int tile = blockIdx.x;
+    const int seg = p.r.tile_seg[tile];
+    if (seg < 0) return;
+    const int nvalid = p.r.tile_valid[tile];
+    const uint8_t* act = active_level(p.mp, p.level) + seg * MAX_TOWER;
+    const uint8_t* mk = p.mp.masks ? p.mp.masks + (size_t)p.mp.seg_dom[seg] * p.mp.edge_count + p.mask_off : nullptr;
+    const int ngate = p.n_t * p.n_src;
+    for (int it = threadIdx.x; it < TILE_M * p.n_t; it += 256) {
+        const int rr = it / p.n_t, t = it - rr * p.n_t;
+        const int64_t row = (int64_t)tile * TILE_M + rr;
+        float* dst = p.In + row * (p.n_t * p.w) + t * p.w;
+        const bool on = rr < nvalid && act[t];
+        float a[MAX_TOWER], am[MAX_TOWER], ah[MAX_TOWER], S;
+        if (on) gate_weights(p.glog + row * p.ld_g + p.goff + t * p.n_src, p.n_src, mk, p.n_t, t, p.mp.mode, a, am, ah, &S);
+        if (p.gate_part && ngate <= MAX_TOWER * MAX_TOWER / 2)
+            for (int s = 0; s < p.n_src; ++s) s_gate[rr][t * p.n_src + s] = on ? am[s] : 0.f;
+        const float* src = p.prev + row * (p.n_src * p.w);
+        for (int c = 0; c < p.w; c += 4) {
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (on)
+                for (int s = 0; s < p.n_src; ++s) {
+                    const float4 x = *(const float4*)(src + s * p.w + c);
+                    o.x += ah[s] * x.x; o.y += ah[s] * x.y; o.z += ah[s] * x.z; o.w += ah[s] * x.w;
+                }
+            *(float4*)(dst + c) = o;
+        }
+    }
+    if (p.gate_part && ngate <= MAX_TOWER * MAX_TOWER / 2) {
+        __syncthreads();
+        for (int gcol = threadIdx.x; gcol < ngate; gcol += 256) {
+            float s = 0.f;
+            for (int rr = 0; rr < TILE_M; ++rr) s += s_gate[rr][gcol];
+            p.gate_part[(int64_t)tile * p.ld_g + p.goff + gcol] = s;
+        }
+    }
+}
+
+// gate statistics: mean over the segment of gate*mask  -> gate_stats[seg][gate_rows]
+__global__ __launch_bounds__(256) void k_gate_stats(const float* gate_part, int ld_g, int gate_rows, float* out, RowsP r) {
+    const int seg = blockIdx.x;
+    const int cnt = r.seg_count[seg];
+    const int t0 = r.seg_start[seg] / TILE_M, nt = (cnt + TILE_M - 1) / TILE_M;
+    for (int c = threadIdx.x; c < gate_rows; c += 256) {
+        float s = 0.f;
+        for (int t = 0; t < nt; ++t) s += gate_part[(int64_t)(t0 + t) * ld_g + c];
+        out[(int64_t)seg * gate_rows + c] = cnt > 0 ? s / (float)cnt : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// heads: z = cn.v[:D] + lin + tower_out.v[D:], p = sigmoid(z)  (aread.py:304-310), fused bagging BCE
+// (run.py:672-677) and its gradient.  One thread per (row, head).
+// ------------------------------------------------------------------------------------------------
+struct HeadsP {
+    const float* hc; const float* lin; const float* act; const float* head_w; int head_ld, D, h, n_heads, ld_h;
+    float* z; float* prob; float* dz; float* probs_out; int64_t B;
+    const float* y; const float* seg_weight; const float* dprobs; float* loss_part; int level;
+    RowsP r; ModeP mp;
+};
+
+__global__ __launch_bounds__(256) void k_heads_fwd(const HeadsP p) {
+    __shared__ float s_loss[256];
+    const int tile = blockIdx.x;
+    const int seg = p.r.tile_seg[tile];
+    if (seg < 0) return;
+    const int nvalid = p.r.tile_valid[tile];
+    const uint8_t* act = active_level(p.mp, p.level) + seg * MAX_TOWER;
+    const float cnt = (float)p.r.seg_count[seg];
+    const float kact = (float)p.mp.kact[seg];
+    float loss = 0.f;
+    for (int it = threadIdx.x; it < TILE_M * p.n_heads; it += 256) {
+        const int rr = it / p.n_heads, i = it - rr * p.n_heads;
+        const int64_t row = (int64_t)tile * TILE_M + rr;
+        const bool on = rr < nvalid && act[i];
+        float z = 0.f, pr = 0.f, dz = 0.f;
+        if (on) {
+            z = p.hc[row * p.ld_h + i] + p.lin[row];
+            const float* a = p.act + row * (p.n_heads * p.h) + i * p.h;
+            const float* v = p.head_w + (int64_t)i * p.head_ld + p.D;
+            for (int c = 0; c < p.h; ++c) z += a[c] * v[c];
+            pr = 1.0f / (1.0f + __expf(-z));
+            const int b = p.r.row_sample[row];
+            if (p.probs_out) p.probs_out[(int64_t)i * p.B + b] = pr;
+            if (p.y) {
+                const float yv = p.y[b];
+                const float lp = fmaxf(__logf(pr), -100.f), lq = fmaxf(__logf(1.0f - pr), -100.f);
+                loss += -(yv * lp + (1.0f - yv) * lq) / (cnt * kact);
+            }
+        }
+        p.z[row * p.ld_h + i] = z;
+        p.prob[row * p.ld_h + i] = pr;
+        (void)dz;
+    }
+    if (p.loss_part) {
+        s_loss[threadIdx.x] = loss;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (threadIdx.x < o) s_loss[threadIdx.x] += s_loss[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) p.loss_part[tile] = s_loss[0];
+    }
+}
+
+// loss_out[0] = sum_seg w_seg * bag_seg, loss_out[1+seg] = bag_seg
+__global__ __launch_bounds__(64) void k_loss_finish(const float* loss_part, const float* seg_weight, float* loss_out, RowsP r) {
+    __shared__ float s_bag[MAX_SEG];
+    const int seg = threadIdx.x;
+    float bag = 0.f;
+    if (seg < r.n_seg) {
+        const int cnt = r.seg_count[seg];
+        const int t0 = r.seg_start[seg] / TILE_M, nt = (cnt + TILE_M - 1) / TILE_M;
+        for (int t = 0; t < nt; ++t) bag += loss_part[t0 + t];
+        loss_out[1 + seg] = bag;
+        bag *= seg_weight ? seg_weight[seg] : 1.f;
+    }
+    s_bag[seg] = bag;
+    __syncthreads();
+    if (seg == 0) {
+        float tot = 0.f;
+        for (int s = 0; s < r.n_seg; ++s) tot += s_bag[s];
+        loss_out[0] = tot;
+    }
+}
+
+// dz = dL/dz for every (row, head): from labels (fused loss) or from an external dL/dprobs.
+__global__ __launch_bounds__(256) void k_heads_dz(const HeadsP p) {
+    const int tile = blockIdx.x;
+    const int seg = p.r.tile_seg[tile];
+    if (seg < 0) return;
+    const int nvalid = p.r.tile_valid[tile];
+    const uint8_t* act = active_level(p.mp, p.level) + seg * MAX_TOWER;
+    const float cnt = (float)p.r.seg_count[seg], kact = (float)p.mp.kact[seg];
+    const float wseg = p.seg_weight ? p.seg_weight[seg] : 1.f;
+    for (int it = threadIdx.x; it < TILE_M * p.ld_h; it += 256) {
+        const int rr = it / p.ld_h, i = it - rr * p.ld_h;
+        const int64_t row = (int64_t)tile * TILE_M + rr;
+        float dz = 0.f;
+        if (i < p.n_heads && rr < nvalid && act[i]) {
+            const float pr = p.prob[row * p.ld_h + i];
+            const int b = p.r.row_sample[row];
+            float dp;
+            if (p.dprobs) dp = p.dprobs[(int64_t)i * p.B + b];
+            else dp = wseg / (cnt * kact) * (pr - p.y[b]) / fmaxf((1.0f - pr) * pr, 1e-12f);   // BCELoss backward
+            dz = dp * pr * (1.0f - pr);                                                           // sigmoid backward
+        }
+        p.dz[row * p.ld_h + i] = dz;
+    }
+}

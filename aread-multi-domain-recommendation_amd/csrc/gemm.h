@@ -1,0 +1,257 @@
+// gemm.h -- grouped fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32
+// products, fp32 accumulate; bit-for-bit a k-ordered fmaf chain).  All dense contractions of the path
+// (expert and tower Linear layers, gate logits, their dgrad and wgrad) go through this one template.
+//
+//   C[g][m][n] (+)= sum_k A[g](m,k) * B[g](n,k)  (+ bias[g][n])
+//
+// Operand element addressing ("KC" = k contiguous, "MC" = m/n contiguous):
+//   A_KC: A[g*a_gs + m*lda + k]      A_MC: A[g*a_gs + k*lda + m]
+//   B_KC: B[g*b_gs + n*ldb + k]      B_MC: B[g*b_gs + k*ldb + n]
+// forward  Y = X W^T      : A_KC (activations), B_KC (torch Linear weight [out,in])
+// dgrad    dX = dY W      : A_KC (dY),          B_MC (W read along its rows)
+// wgrad    dW = dY^T X    : A_MC (dY),          B_MC (X), K = batch rows, split-K into slabs
+//
+// Workgroup = 256 threads = 4 waves stacked along M (16 rows each) -> 64 x (16*NI) output tile,
+// BK = 32.  LDS tiles are [rows][BK+2] so that the fragment reads (lane -> row l&15, k l>>4) hit 32
+// distinct banks.  Global loads are 16 B per lane along the contiguous axis and are prefetched into
+// registers one k-tile ahead of the MFMAs.
+#pragma once
+#include "common.h"
+
+#define GEMM_THREADS 256
+#define GEMM_BK 32
+#define GEMM_PITCH (GEMM_BK + 2)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct GemmP {
+    const float* A; int64_t lda, a_gs;
+    const float* B; int64_t ldb, b_gs;
+    float* C; int64_t ldc, c_gs, c_ks;       // c_ks: slab stride for split-K outputs
+    const float* bias; int64_t bias_gs;
+    int M, N, K, G;
+    int accumulate;
+    int k_split, k_chunk;                    // K is cut into k_split slices of k_chunk (multiple of 64)
+    // gating.  m_gate: M is the batch axis (tile_seg indexes 64-row m-tiles); k_gate: K is the batch axis
+    const int32_t* tile_seg;                 // nullable; -1 = unused tile
+    const int32_t* tile_valid;               // valid rows per tile (for the statistics epilogue)
+    const uint8_t* active; int active_ld;    // nullable; active[seg*active_ld + g]
+    int gate_axis;                           // 0 none, 1 = M, 2 = K
+    // BatchNorm statistics epilogue (forward): per m-tile, per column: (mean, M2) over the valid rows
+    float* stat_part; int64_t stat_ld;       // stat_part[(tile_m*stat_ld + g*N + n)*2 + {0,1}]
+};
+
+template <int ROWS, bool KC>
+struct TileLoader {
+    // number of float4 each thread moves per k-tile
+    static constexpr int F4 = (ROWS * GEMM_BK / 4 + GEMM_THREADS - 1) / GEMM_THREADS;
+    float4 v[F4];
+
+    __device__ __forceinline__ void load(const float* __restrict__ base, int64_t ld, int r0, int r_end, int k0,
+                                         int k_end) {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int p = 0; p < F4; ++p) {
+            const int idx = tid + p * GEMM_THREADS;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (KC) {
+                const int row = idx >> 3, kq = idx & 7;                 // 8 float4 per row of BK=32
+                if (row < ROWS) {
+                    const int r = r0 + row, k = k0 + 4 * kq;
+                    if (r < r_end) {
+                        const float* ptr = base + (int64_t)r * ld + k;
+                        if (k + 3 < k_end) t = *(const float4*)ptr;
+                        else {
+                            if (k < k_end) t.x = ptr[0];
+                            if (k + 1 < k_end) t.y = ptr[1];
+                            if (k + 2 < k_end) t.z = ptr[2];
+                        }
+                    }
+                }
+            } else {
+                constexpr int Q = ROWS / 4;                              // float4 per k-row
+                const int krow = idx / Q, mq = idx - krow * Q;
+                if (krow < GEMM_BK) {
+                    const int k = k0 + krow, r = r0 + 4 * mq;
+                    if (k < k_end) {
+                        const float* ptr = base + (int64_t)k * ld + r;
+                        if (r + 3 < r_end) t = *(const float4*)ptr;
+                        else {
+                            if (r < r_end) t.x = ptr[0];
+                            if (r + 1 < r_end) t.y = ptr[1];
+                            if (r + 2 < r_end) t.z = ptr[2];
+                        }
+                    }
+                }
+            }
+            v[p] = t;
+        }
+    }
+
+    __device__ __forceinline__ void store(float* __restrict__ lds) const {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int p = 0; p < F4; ++p) {
+            const int idx = tid + p * GEMM_THREADS;
+            if (KC) {
+                const int row = idx >> 3, kq = idx & 7;
+                if (row < ROWS) {
+                    float* d = lds + row * GEMM_PITCH + 4 * kq;
+                    *(float2*)d = make_float2(v[p].x, v[p].y);
+                    *(float2*)(d + 2) = make_float2(v[p].z, v[p].w);
+                }
+            } else {
+                constexpr int Q = ROWS / 4;
+                const int krow = idx / Q, mq = idx - krow * Q;
+                if (krow < GEMM_BK) {
+                    float* d = lds + (4 * mq) * GEMM_PITCH + krow;
+                    d[0] = v[p].x;
+                    d[GEMM_PITCH] = v[p].y;
+                    d[2 * GEMM_PITCH] = v[p].z;
+                    d[3 * GEMM_PITCH] = v[p].w;
+                }
+            }
+        }
+    }
+};
+
+template <int NI, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(GEMM_THREADS) void k_gemm(const GemmP p) {
+    constexpr int TM = 64, TN = 16 * NI;
+    __shared__ __attribute__((aligned(16))) float As[TM * GEMM_PITCH];
+    __shared__ __attribute__((aligned(16))) float Bs[TN * GEMM_PITCH];
+    __shared__ float s_red[4][TN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.z / p.k_split, ks = blockIdx.z - g * p.k_split;
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+
+    int seg = 0;
+    if (p.gate_axis == 1) {
+        seg = p.tile_seg[blockIdx.y];
+        if (seg < 0) return;
+        if (p.active && !p.active[seg * p.active_ld + g]) return;
+    }
+    const float* Ag = p.A + (int64_t)g * p.a_gs;
+    const float* Bg = p.B + (int64_t)g * p.b_gs;
+    const int k_begin = ks * p.k_chunk;
+    int k_end = k_begin + p.k_chunk;
+    if (k_end > p.K) k_end = p.K;
+
+    f32x4 acc[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto tile_live = [&](int k0) -> bool {
+        if (p.gate_axis != 2) return true;
+        const int s = p.tile_seg[k0 / TILE_M];
+        if (s < 0) return false;
+        return !(p.active && !p.active[s * p.active_ld + g]);
+    };
+    auto next_live = [&](int k0) -> int {
+        while (k0 < k_end && !tile_live(k0)) k0 += GEMM_BK;
+        return k0;
+    };
+
+    TileLoader<TM, A_KC> la;
+    TileLoader<TN, B_KC> lb;
+    int k0 = next_live(k_begin);
+    if (k0 < k_end) {
+        la.load(Ag, p.lda, m0, p.M, k0, k_end);
+        lb.load(Bg, p.ldb, n0, p.N, k0, k_end);
+    }
+    const int fr = lane & 15, fk = lane >> 4;
+    while (k0 < k_end) {
+        la.store(As);
+        lb.store(Bs);
+        __syncthreads();
+        const int kn = next_live(k0 + GEMM_BK);
+        if (kn < k_end) {
+            la.load(Ag, p.lda, m0, p.M, kn, k_end);
+            lb.load(Bg, p.ldb, n0, p.N, kn, k_end);
+        }
+        const float* ap = As + (wave * 16 + fr) * GEMM_PITCH + fk;
+        const float* bp = Bs + fr * GEMM_PITCH + fk;
+#pragma unroll
+        for (int kk = 0; kk < GEMM_BK / 4; ++kk) {
+            const float a = ap[kk * 4];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const float b = bp[i * 16 * GEMM_PITCH + kk * 4];
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        k0 = kn;
+    }
+
+    // ---- epilogue: C/D layout col = lane&15, row = (lane>>4)*4 + reg -------------------------------
+    const int col_in = lane & 15, row_base = wave * 16 + (lane >> 4) * 4;
+    float* Cg = p.C + (int64_t)g * p.c_gs + (int64_t)ks * p.c_ks;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int n = n0 + i * 16 + col_in;
+        if (n < p.N) {
+            const float bv = p.bias ? p.bias[(int64_t)g * p.bias_gs + n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[i][r] += bv;
+                const int m = m0 + row_base + r;
+                if (m < p.M) {
+                    float* c = Cg + (int64_t)m * p.ldc + n;
+                    *c = p.accumulate ? *c + acc[i][r] : acc[i][r];
+                }
+            }
+        }
+    }
+    if (p.stat_part) {
+        const int nvalid = p.tile_valid[blockIdx.y];
+        // pass 1: column sums over valid rows
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s += (row_base + r < nvalid) ? acc[i][r] : 0.f;
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (lane < 16) s_red[wave][i * 16 + lane] = s;
+        }
+        __syncthreads();
+        float mean[NI];
+        const float inv = 1.0f / (float)nvalid;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int c = i * 16 + col_in;
+            mean[i] = ((s_red[0][c] + s_red[1][c]) + (s_red[2][c] + s_red[3][c])) * inv;
+        }
+        __syncthreads();
+        // pass 2: centred sum of squares
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = acc[i][r] - mean[i];
+                s += (row_base + r < nvalid) ? d * d : 0.f;
+            }
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (lane < 16) s_red[wave][i * 16 + lane] = s;
+        }
+        __syncthreads();
+        if (wave == 0 && lane < 16) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int c = i * 16 + lane, n = n0 + c;
+                if (n < p.N) {
+                    const float m2 = (s_red[0][c] + s_red[1][c]) + (s_red[2][c] + s_red[3][c]);
+                    float* o = p.stat_part + ((int64_t)blockIdx.y * p.stat_ld + (int64_t)g * p.N + n) * 2;
+                    o[0] = mean[i];
+                    o[1] = m2;
+                }
+            }
+        }
+    }
+}
+
+int launch_gemm(const GemmP& p, bool a_kc, bool b_kc, hipStream_t st);

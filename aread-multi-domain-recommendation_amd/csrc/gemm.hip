@@ -1,0 +1,48 @@
+// gemm.hip -- instantiations + launcher of the grouped fp32-MFMA GEMM (see gemm.h).
+#include "gemm.h"
+
+template <int NI>
+static void launch_ni(const GemmP& p, bool a_kc, bool b_kc, dim3 grid, hipStream_t st) {
+    if (a_kc && b_kc) hipLaunchKernelGGL((k_gemm<NI, true, true>), grid, dim3(GEMM_THREADS), 0, st, p);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((k_gemm<NI, true, false>), grid, dim3(GEMM_THREADS), 0, st, p);
+    else if (!a_kc && !b_kc) hipLaunchKernelGGL((k_gemm<NI, false, false>), grid, dim3(GEMM_THREADS), 0, st, p);
+    else hipLaunchKernelGGL((k_gemm<NI, false, true>), grid, dim3(GEMM_THREADS), 0, st, p);
+}
+
+int launch_gemm(const GemmP& p_in, bool a_kc, bool b_kc, hipStream_t st) {
+    GemmP p = p_in;
+    AR_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0 && p.G > 0, "gemm: empty problem M=%d N=%d K=%d G=%d", p.M, p.N, p.K, p.G);
+    AR_CHECK_ARG(p.lda % 4 == 0 && p.ldb % 4 == 0 && p.a_gs % 4 == 0 && p.b_gs % 4 == 0,
+                 "gemm: leading dimensions / group strides must be multiples of 4 (lda=%lld ldb=%lld)",
+                 (long long)p.lda, (long long)p.ldb);
+    AR_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.B & 15) == 0, "gemm: operands must be 16-byte aligned");
+    if (p.k_split < 1) p.k_split = 1;
+    if (p.k_split == 1) p.k_chunk = p.K;
+    AR_CHECK_ARG(p.k_split == 1 || p.k_chunk % TILE_M == 0, "gemm: k_chunk must be a multiple of %d", TILE_M);
+    AR_CHECK_ARG(p.gate_axis == 0 || p.tile_seg != nullptr, "gemm: gating needs tile_seg");
+    const int ni = p.N > 64 ? 8 : (p.N > 32 ? 4 : (p.N > 16 ? 2 : 1));
+    dim3 grid(cdiv(p.N, 16 * ni), cdiv(p.M, 64), p.G * p.k_split);
+    switch (ni) {
+        case 8: launch_ni<8>(p, a_kc, b_kc, grid, st); break;
+        case 4: launch_ni<4>(p, a_kc, b_kc, grid, st); break;
+        case 2: launch_ni<2>(p, a_kc, b_kc, grid, st); break;
+        default: launch_ni<1>(p, a_kc, b_kc, grid, st); break;
+    }
+    AR_LAUNCH_CHECK();
+    return AREAD_OK;
+}
+
+extern "C" int aread_gemm(const float* A, int64_t lda, int64_t a_gs, int a_kc, const float* B, int64_t ldb,
+                          int64_t b_gs, int b_kc, float* C, int64_t ldc, int64_t c_gs, const float* bias,
+                          int64_t bias_gs, int M, int N, int K, int G, int accumulate, void* stream) {
+    GemmP p = {};
+    p.A = A; p.lda = lda; p.a_gs = a_gs;
+    p.B = B; p.ldb = ldb; p.b_gs = b_gs;
+    p.C = C; p.ldc = ldc; p.c_gs = c_gs; p.c_ks = 0;
+    p.bias = bias; p.bias_gs = bias_gs;
+    p.M = M; p.N = N; p.K = K; p.G = G;
+    p.accumulate = accumulate;
+    p.k_split = 1; p.k_chunk = K;
+    AR_CHECK_ARG(A && B && C, "aread_gemm: null pointer");
+    return launch_gemm(p, a_kc != 0, b_kc != 0, (hipStream_t)stream);
+}

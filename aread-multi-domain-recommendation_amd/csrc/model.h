@@ -1,0 +1,63 @@
+// model.h -- host-side layouts of the dense model: flat parameter / statistics buffers and the
+// per-call workspace.  Pure bookkeeping; no device memory is owned here.
+#pragma once
+#include <string>
+#include <vector>
+#include "common.h"
+
+#define MAX_TOWER 16      // towers per level
+#define MAX_CROSS 4
+
+struct LayerL {              // one (grouped) Linear+BatchNorm layer of an MLP stack
+    int G, in_dim, out_dim;  // G groups (experts / towers of a level)
+    int ncols;               // G*out_dim
+    int in_ld;               // leading dimension of the input activation buffer
+    int64_t in_gs;           // per-group offset in the input buffer (0 = all groups share the input)
+    int stack, layer;        // dropout site ids (stack 0 = experts, 1+l = tower level l)
+    // params (floats into the flat buffer)
+    int64_t w, b, gamma, beta;
+    // stats buffer
+    int64_t rmean, rvar;
+    int nbt0;                // first num_batches_tracked counter (one per group)
+};
+
+struct LayerWs {             // workspace of one layer (float offsets)
+    int64_t H, Act, dAct, part, mean, rstd, var, bpart, s12, cpart;
+};
+
+struct StackL {
+    int n_layers;
+    LayerL L[AREAD_MAX_LAYER];
+};
+
+struct aread_model {
+    aread_model_cfg cfg;
+    int D, E, n_heads, h_last, head_ld;     // head_ld = D + h_last
+    StackL experts;
+    StackL towers[AREAD_MAX_LEVEL];
+    // params
+    int64_t lin_w, lin_b, cn_w, cn_b, gate_w, gate_b, group_emb, tgate_w, tgate_b, head_w;
+    int64_t n_params, n_stats;
+    int n_bn;
+    // masks
+    int edge_count;
+    int mask_off[AREAD_MAX_LEVEL + 1];      // byte offset of each level inside one domain's mask
+    int gate_rows;                           // sum_l n_l * n_{l-1}
+    int gate_off[AREAD_MAX_LEVEL];           // first gate row of level l (l >= 1)
+    int ld_ge, ld_gt, ld_h;                  // padded leading dims: MMoE gate logits, tower gate logits, heads
+    std::vector<aread_tensor_desc> tensors;
+};
+
+struct WsLayout {                            // float offsets into the workspace (computed per (B, n_seg))
+    int64_t max_rows, n_tiles;
+    int64_t cn, lin, xw, q, glogE, glogT, hc, z, prob, dz, dlin, dcn, dq, dglogE, dglogT, grp, dgrp_part;
+    int64_t In[AREAD_MAX_LEVEL], dIn[AREAD_MAX_LEVEL];
+    LayerWs ex[AREAD_MAX_LAYER];
+    LayerWs tw[AREAD_MAX_LEVEL][AREAD_MAX_LAYER];
+    int64_t active;                          // bytes region (as float offset): [n_level][MAX_SEG][MAX_TOWER]
+    int64_t kact, seg_dom;                   // ints: active heads per seg, domain of each seg
+    int64_t loss_part, gate_part, slab, rw_part, misc_part;
+    int64_t total;                           // floats
+};
+
+void ws_layout(const aread_model* m, int64_t B, int n_seg, WsLayout* w);

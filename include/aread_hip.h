@@ -105,6 +105,102 @@ int aread_l2_table(const float* w, int64_t n, float l2, float grad_scale, float*
 int aread_l2_finish(const float* partial, int n_partial, float l2, float* loss_out, int accumulate,
                     void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Grouped fp32 GEMM on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32 products):
+ *     C[g][m][n] (+)= sum_k A[g](m,k) * B[g](n,k) (+ bias[g][n])
+ * a_kc / b_kc != 0: the operand is k-contiguous (element (r,k) at base + g*gs + r*ld + k);
+ *           == 0: it is row-contiguous     (element (r,k) at base + g*gs + k*ld + r).
+ * Building block of every Linear layer on the path: torch.nn.Linear inside MultiLayerPerceptron
+ * (model/layer.py:209-229), the MMoE / tower gates (model/aread.py:96-99,111-114) and their autograd.
+ * ld and group strides must be multiples of 4 floats, base pointers 16-byte aligned.
+ * ------------------------------------------------------------------------------------------- */
+int aread_gemm(const float* A, int64_t lda, int64_t a_gs, int a_kc,
+               const float* B, int64_t ldb, int64_t b_gs, int b_kc,
+               float* C, int64_t ldc, int64_t c_gs, const float* bias, int64_t bias_gs,
+               int M, int N, int K, int G, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense part of the model: linear term, cross network, MMoE bottom, masked HEI tower pyramid, heads,
+ * bagging loss -- forward and backward.  Replaces AREAD.forward / hier_tower_mask_forward
+ * (model/aread.py:129-322), MultiLayerPerceptron.forward (model/layer.py:221-229),
+ * CrossNetwork.forward (model/layer.py:529-537), FeaturesLinear (model/layer.py:115-126), the dense
+ * terms of get_regularization_loss (model/layer.py:96-112) and the step closure (run.py:672-680).
+ *
+ * aread_model is a host-side handle that only holds layouts (it owns no device memory):
+ *   params : one flat fp32 buffer with every trainable dense tensor (layout: aread_model_tensor)
+ *   stats  : one flat fp32 buffer with the BatchNorm running_mean / running_var vectors
+ *   nbt    : int64 num_batches_tracked counters, one per BatchNorm module
+ *   ws     : workspace of aread_model_workspace_bytes(m, B, n_seg) bytes (activations, partials)
+ * Every tensor of the reference's state_dict is a contiguous slice of params/stats/nbt.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct aread_model_cfg {
+    int32_t embed_dim, f_out, domain_field;       /* D = f_out*embed_dim; output-field index of the domain id */
+    int32_t n_expert, n_expert_layers, expert_dims[AREAD_MAX_LAYER];
+    int32_t n_level, n_tower[AREAD_MAX_LEVEL], n_tower_layers, tower_dims[AREAD_MAX_LEVEL][AREAD_MAX_LAYER];
+    int32_t n_cross, n_domain;
+    float dropout;
+    float l2_linear, l2_dnn, l2_cross;
+} aread_model_cfg;
+
+typedef struct aread_tensor_desc {
+    char name[96];          /* the reference's state_dict key */
+    int32_t kind;           /* 0 = params, 1 = stats, 2 = nbt counter */
+    int32_t ndim;
+    int64_t offset;         /* element offset inside the buffer named by kind */
+    int64_t shape[2];
+    float l2;               /* L2 coefficient of this tensor in the regulariser (0 = not regularised) */
+} aread_tensor_desc;
+
+typedef struct aread_model aread_model;
+int aread_model_create(const aread_model_cfg* cfg_host, aread_model** out_host);
+void aread_model_destroy(aread_model* m);
+int64_t aread_model_param_floats(const aread_model* m);
+int64_t aread_model_stat_floats(const aread_model* m);
+int aread_model_n_bn(const aread_model* m);
+int aread_model_n_tensors(const aread_model* m);
+int aread_model_tensor(const aread_model* m, int i, aread_tensor_desc* out_host);
+int aread_model_edge_count(const aread_model* m);      /* bytes per domain in `masks` */
+int aread_model_gate_rows(const aread_model* m);       /* sum_l n_l*n_{l-1}: columns of gate_stats */
+int64_t aread_model_workspace_bytes(const aread_model* m, int64_t B, int n_seg);
+
+typedef struct aread_call {
+    int64_t B;
+    int32_t n_seg;            /* 1: one BN segment (single-domain batch or wo_mask); else n_domain */
+    int32_t mode;             /* 0 = masked HEI (domain_mask_bagging / domain_with_mask), 1 = wo_mask */
+    int32_t train;            /* 1: batch statistics + dropout (model.train()); 0: running statistics */
+    int32_t update_running;   /* 1: update running_mean/var/num_batches_tracked (train only) */
+    int32_t domain;           /* n_seg == 1: domain_i of the call (selects the mask); ignored otherwise */
+    uint32_t drop_seed;
+    const int32_t* plan;      /* aread_plan_build(x, B, ..., n_seg) */
+    const uint8_t* masks;     /* [n_domain][edge_count] bytes, level-major, row-major (mode 0) */
+    const float* params;
+    float* stats;
+    int64_t* nbt;
+    void* ws;
+    float* probs;             /* out: [n_heads][B] in sample order; 0 where the head is inactive */
+    float* gate_stats;        /* out (optional): [n_seg][gate_rows] mean over the segment of gate*mask */
+    const float* y;           /* optional labels [B] (float 0/1): enables the fused loss + its gradient */
+    const float* seg_weight;  /* optional [n_seg] weights w_d of the per-domain bagging losses (default 1) */
+    float* loss_out;          /* optional out: [1 + n_seg]: sum_d w_d*bag_d, then bag_d per segment */
+} aread_call;
+
+/* e_in: embedding output in plan order [plan.max_rows][D] (aread_embed_fwd with the plan's row_sample). */
+int aread_forward(const aread_model* m, const aread_call* call_host, const float* e_in, void* stream);
+/* Backward of the same call (the workspace must be untouched since aread_forward).
+ * dprobs: gradient w.r.t. probs [n_heads][B] (sample order), or NULL to use the fused loss gradient
+ * (requires call.y).  grads: flat buffer like params, OVERWRITTEN with the gradient.
+ * de_out: [plan.max_rows][D], overwritten with the gradient w.r.t. e_in. */
+int aread_backward(const aread_model* m, const aread_call* call_host, const float* e_in, const float* dprobs,
+                   float* grads, float* de_out, void* stream);
+/* Dense L2 terms: loss_out[0] (+)= sum_i coef[i]*w[i]^2, grads[i] += 2*coef[i]*w[i] (grads may be NULL).
+ * coef: device vector like params (aread_model_l2_coef fills a host copy).
+ * loss_out must have room for 65 floats: [0] is the result, [1..64] is scratch for block partials. */
+int aread_model_l2_coef(const aread_model* m, float* coef_host);
+/* Test/debug introspection: float offset of a named workspace buffer (e.g. "cn", "ex0.H", "tw1.0.Act"), -1 if unknown. */
+int64_t aread_debug_ws_offset(const aread_model* m, int64_t B, int n_seg, const char* name);
+int aread_l2_dense(const float* params, const float* coef, int64_t n, float* grads, float* loss_out,
+                   int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

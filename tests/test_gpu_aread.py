@@ -1,0 +1,201 @@
+"""GPU parity of the whole path (embedding + dense model, forward and backward) through the C ABI,
+against the golden vectors recorded from the reference and against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import aread_oracle as O
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+TOL = dict(rtol=1e-4, atol=1e-5)      # north_star: logits within 1e-4 relative
+
+
+def tmask(mask, dev="cuda"):
+    return [torch.tensor(np.asarray(m), dtype=torch.bool, device=dev) for m in mask]
+
+
+def all_grads(model):
+    g = U.dense_grads(model)
+    g["embedding.embedding_dict.weight"] = model.embedding.embedding_dict.weight.grad.detach().cpu().numpy()
+    return g
+
+
+def logits_of(p):
+    return np.log(p) - np.log1p(-p)
+
+
+@pytest.mark.parametrize("which", ["full", "tiny"])
+def test_state_dict_roundtrip(which):
+    fn, mk, seed = U.GOLDEN_MODELS[which]
+    spec = mk()
+    model, P = U.build_model(spec, seed)
+    sd = model.state_dict()
+    assert set(sd.keys()) == set(P.keys())
+    for k, v in P.items():
+        assert tuple(sd[k].shape) == tuple(v.shape), k
+        assert torch.equal(sd[k].cpu(), v), k
+
+
+@pytest.mark.parametrize("which", ["full", "tiny"])
+@pytest.mark.parametrize("mname", ["ones", "rand", "sparse"])
+def test_single_domain_bagging_step_autograd(which, mname):
+    """The drop-in path: model(X, 'domain_mask_bagging') + BCELoss per head + reg, loss.backward() (run.py:668-680)."""
+    fn, mk, seed = U.GOLDEN_MODELS[which]
+    G, spec = U.load_golden(fn), mk()
+    model, _ = U.build_model(spec, seed)
+    model.train()
+    model.reset_for_mask_update() if hasattr(model, "reset_for_mask_update") else None
+    p = f"single_{mname}"
+    d = int(G[f"{p}/domain"])
+    masks = U.golden_masks(spec, G, mname)
+    x = torch.from_numpy(G[f"{p}/x"]).cuda()
+    y = torch.from_numpy(G[f"{p}/y"].astype(np.float32)).cuda()
+    preds = model(x, mode="domain_mask_bagging", domain_i=d, current_mask=tmask(masks[d]), tmp_memory_gate_value=True)
+    crit = torch.nn.BCELoss()
+    bag = sum(crit(pr, y) for pr in preds.unbind(dim=0)) / preds.shape[0]
+    reg = model.get_regularization_loss(device="cuda")
+    loss = bag + reg
+    model.zero_grad()
+    loss.backward()
+    ref = G[f"{p}/probs"]
+    act = ~np.isnan(ref[:, 0])
+    assert preds.shape[0] == act.sum()
+    got = preds.detach().cpu().numpy()
+    np.testing.assert_allclose(logits_of(got), G[f"{p}/logits"][act], **TOL)
+    np.testing.assert_allclose(got, ref[act], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose([float(loss), float(bag), float(reg)], G[f"{p}/loss"], rtol=2e-5)
+    for l in range(1, spec.n_level):
+        g = torch.stack(model.tmp_tower_gate_values[l], dim=1).cpu().numpy()
+        np.testing.assert_allclose(g, G[f"{p}/gate{l}"], rtol=1e-4, atol=1e-6)
+    U.check_grads(G, f"{p}/grad", all_grads(model), rtol=5e-4, atol_scale=5e-5)
+    sd = model.state_dict()
+    for k in sd:
+        if k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+            np.testing.assert_allclose(sd[k].cpu().numpy(), G[f"{p}/buf/{k}"], rtol=1e-4, atol=1e-6, err_msg=k)
+
+
+@pytest.mark.parametrize("which", ["full", "tiny"])
+def test_multi_domain_fused_step(which):
+    """The fused 'N-domain batch' step (ragged: one empty domain, one single-row domain) vs the reference's
+    per-domain calls."""
+    fn, mk, seed = U.GOLDEN_MODELS[which]
+    G, spec = U.load_golden(fn), mk()
+    model, _ = U.build_model(spec, seed)
+    model.train()
+    masks = U.golden_masks(spec, G, "rand")
+    model.domain_mask = [tmask(m) for m in masks]
+    x = torch.from_numpy(G["multi_rand/x"]).cuda()
+    y = torch.from_numpy(G["multi_rand/y"].astype(np.float32)).cuda()
+    bufs = model.make_step_buffers(x.shape[0], multi_domain=True)
+    loss = model.train_step(x, y, bufs, want_gates=True)
+    torch.cuda.synchronize()
+    ref = G["multi_rand/probs"]
+    ok = ~np.isnan(ref)
+    got = bufs["probs"].cpu().numpy()
+    assert (got[~ok] == 0).all()
+    np.testing.assert_allclose(logits_of(got[ok]), G["multi_rand/logits"][ok], **TOL)
+    np.testing.assert_allclose([float(loss), float(bufs["loss"][0]), float(bufs["reg"][0])], G["multi_rand/loss"], rtol=2e-5)
+    st, gate = model._last
+    gate = gate.cpu().numpy()
+    for d in range(spec.n_domain):
+        if f"multi_rand/gate1/d{d}" not in G:
+            continue
+        off = 0
+        for l in range(1, spec.n_level):
+            n = spec.n_tower[l] * spec.n_tower[l - 1]
+            g = gate[d, off:off + n].reshape(spec.n_tower[l], spec.n_tower[l - 1]).T
+            np.testing.assert_allclose(g, G[f"multi_rand/gate{l}/d{d}"], rtol=1e-4, atol=1e-6)
+            off += n
+    U.check_grads(G, "multi_rand/grad", all_grads(model), rtol=5e-4, atol_scale=5e-5)
+    sd = model.state_dict()
+    for k in sd:
+        if k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+            np.testing.assert_allclose(sd[k].cpu().numpy(), G[f"multi_rand/buf/{k}"], rtol=1e-4, atol=1e-6, err_msg=k)
+
+
+@pytest.mark.parametrize("which", ["full", "tiny"])
+def test_eval_domain_with_mask(which):
+    fn, mk, seed = U.GOLDEN_MODELS[which]
+    G, spec = U.load_golden(fn), mk()
+    model, _ = U.build_model(spec, seed)
+    model.eval()
+    d = int(G["eval_with_mask/domain"])
+    masks = U.golden_masks(spec, G, "rand")
+    with torch.no_grad():
+        yv = model(torch.from_numpy(G["eval_with_mask/x"]).cuda(), mode="domain_with_mask", domain_i=d,
+                   current_mask=tmask(masks[d]))
+    np.testing.assert_allclose(yv.cpu().numpy(), G["eval_with_mask/y"], rtol=1e-5, atol=1e-6)
+    sd = model.state_dict()
+    P = O.init_params(spec, seed)
+    for k in sd:
+        if k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+            assert torch.equal(sd[k].cpu(), P[k]), k            # eval never touches the running statistics
+
+
+@pytest.mark.parametrize("which", ["full", "tiny"])
+def test_wo_mask_warmup_step(which):
+    fn, mk, seed = U.GOLDEN_MODELS[which]
+    G, spec = U.load_golden(fn), mk()
+    model, _ = U.build_model(spec, seed)
+    model.train()
+    model.reset_for_mask_update()
+    d = int(G["wo_mask/domain"])
+    x = torch.from_numpy(G["wo_mask/x"]).cuda()
+    y = torch.from_numpy(G["wo_mask/y"].astype(np.float32)).cuda()
+    pred = model(x, mode="wo_mask", domain_i=d, memory_gate_value=True)
+    assert tuple(pred.shape) == (x.shape[0], 1)
+    loss = torch.nn.BCELoss()(pred.squeeze(), y)
+    reg = model.get_regularization_loss(device="cuda")
+    model.zero_grad()
+    (loss + reg).backward()
+    np.testing.assert_allclose(pred.detach().cpu().numpy(), G["wo_mask/pred"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose([float(loss + reg), float(loss), float(reg)], G["wo_mask/loss"], rtol=2e-5)
+    for l in range(1, spec.n_level):
+        g = torch.stack([model.domain_tower_gate_values[d][l][t][0] for t in range(spec.n_tower[l])], dim=1).cpu().numpy()
+        np.testing.assert_allclose(g, G[f"wo_mask/gate{l}"], rtol=1e-4, atol=1e-6)
+    U.check_grads(G, "wo_mask/grad", all_grads(model), rtol=5e-4, atol_scale=5e-5)
+
+
+@pytest.mark.parametrize("which", ["full", "tiny"])
+def test_one_row_call_skips_batchnorm(which):
+    fn, mk, seed = U.GOLDEN_MODELS[which]
+    G, spec = U.load_golden(fn), mk()
+    model, _ = U.build_model(spec, seed)
+    model.train()
+    masks = U.golden_masks(spec, G, "rand")
+    model.domain_mask = [tmask(m) for m in masks]
+    x = torch.from_numpy(G["one_row/x"]).cuda()
+    y = torch.from_numpy(G["one_row/y"].astype(np.float32)).cuda()
+    bufs = model.make_step_buffers(1, multi_domain=True)
+    loss = model.train_step(x, y, bufs)
+    ok = ~np.isnan(G["one_row/probs"])
+    np.testing.assert_allclose(bufs["probs"].cpu().numpy()[ok], G["one_row/probs"][ok], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(float(loss), G["one_row/loss"][0], rtol=2e-5)
+    U.check_grads(G, "one_row/grad", all_grads(model), rtol=5e-4, atol_scale=5e-5)
+
+
+def test_dropout_matches_oracle_hash():
+    """p = 0.2 in train mode: the kernels and the oracle share the counter-based keep mask bit for bit."""
+    spec = U.spec_full(dropout=0.2)
+    seed = 123
+    G = U.load_golden("aread_full.npz")
+    model, P = U.build_model(spec, seed)
+    model.train()
+    model.drop_seed = 777
+    masks = U.golden_masks(spec, G, "rand")
+    model.domain_mask = [tmask(m) for m in masks]
+    x, y = G["multi_rand/x"], G["multi_rand/y"]
+    bufs = model.make_step_buffers(x.shape[0], multi_domain=True)
+    loss = model.train_step(torch.from_numpy(x).cuda(), torch.from_numpy(y.astype(np.float32)).cuda(), bufs)
+    r = O.step(P, spec, x, y, masks, drop_seed=777)
+    ok = ~np.isnan(r["probs"])
+    np.testing.assert_allclose(logits_of(bufs["probs"].cpu().numpy()[ok]), r["logits"][ok], **TOL)
+    np.testing.assert_allclose(float(loss), r["loss"], rtol=2e-5)
+    got = all_grads(model)
+    for k, v in r["grads"].items():
+        ref = v.numpy()
+        if k not in got:                      # dead parameters (attention branch, final_gate): no gradient
+            assert not ref.any(), k
+            continue
+        np.testing.assert_allclose(got[k], ref, rtol=1e-3, atol=5e-5 * max(np.abs(ref).max(), 1e-4), err_msg=k)

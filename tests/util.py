@@ -63,3 +63,41 @@ def check_grads(G, prefix, grads, rtol=2e-4, atol_scale=2e-5, skip=(), floor=2e-
         n += 1
     assert n > 0, f"no golden gradients under {prefix}"
     return n
+
+
+# ---- helpers for the HIP-side model (GPU tests, smoke, bench) ---------------------------------------
+def model_config(spec):
+    import types
+    cfg = types.SimpleNamespace()
+    cfg.dataset_name = "synthetic"
+    cfg.domain_size = {"synthetic": [100 + d for d in range(spec.n_domain)]}
+    cfg.use_dcn, cfg.use_atten = True, bool(spec.with_dead_attention)
+    cfg.n_cross_layers, cfg.mmoe_n_expert = spec.n_cross, spec.n_expert
+    cfg.atten_embed_dim, cfg.att_layer_num, cfg.att_head_num, cfg.att_res = spec.atten_embed_dim, spec.att_layer_num, 2, True
+    return cfg
+
+
+def build_model(spec, seed, device="cuda", dropout=None):
+    """aread_amd.AREAD with the parameters of oracle.init_params(spec, seed) (strict state_dict load)."""
+    import aread_amd
+    mh = {"multi_hot_flag": list(spec.multi_hot_flag), "itemid_idx": spec.itemid_idx, "seq_maxlen": spec.seq_maxlen,
+          "method": spec.method}
+    model = aread_amd.AREAD(list(spec.field_dims), spec.embed_dim, mh, tuple(spec.n_tower), spec.n_domain, "mmoe",
+                            tuple(spec.expert_dims), tuple(tuple(t) for t in spec.tower_dims), spec.domain_idx,
+                            n_cross_layers=spec.n_cross, dropout=spec.dropout if dropout is None else dropout,
+                            device=device, l2_reg_embedding=spec.l2_embedding, l2_reg_linear=spec.l2_linear,
+                            l2_reg_dnn=spec.l2_dnn, l2_reg_cross=spec.l2_cross, config=model_config(spec))
+    P = O.init_params(spec, seed)
+    model.load_state_dict(P, strict=True)
+    return model.to(device), P
+
+
+def dense_grads(model, flat=None):
+    """name -> numpy gradient for every tensor that lives in the flat dense parameter."""
+    g = (model.dense.grad if flat is None else flat).detach().cpu().numpy()
+    out = {}
+    for name, kind, off, shape, _ in model._tensors:
+        if kind == 0:
+            n = int(np.prod(shape)) if shape else 1
+            out[name] = g[off:off + n].reshape(shape)
+    return out
