@@ -1,0 +1,246 @@
+#!/usr/bin/env python
+"""bench.py -- CTR samples/s of one AREAD forward+backward step (25-domain batch, B=8192 per GPU).
+
+A step = embedding gather/pool -> trunk -> MMoE -> masked HEI towers -> heads -> bagging BCE + L2
+-> backward to every parameter gradient (dense 178 MB table gradient included; optimizer excluded,
+as SURVEY.md 8d defines the metric), on a synthetic Amazon-like 25-domain batch resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for every field.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured float4 copy)
+F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 runs at the fp32 vector peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8192, help="samples per GPU per step")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--dropout", type=float, default=0.2)
+    ap.add_argument("--domain-dist", default="proportional", choices=["proportional", "uniform"])
+    return ap.parse_args()
+
+
+def build(spec, device, seed=123):
+    from tests.util import build_model
+    model, P = build_model(spec, seed, device=device)
+    model.train()
+    return model, P
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def main():
+    args = parse()
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from oracle import aread_oracle as O          # spec + deterministic initialiser (+ cpu_baseline leg below)
+    from tools import synth
+    import aread_amd
+    from aread_amd import _lib as L
+
+    spec = O.amazon_spec(dropout=args.dropout)
+    B = args.batch
+    rng = np.random.default_rng(2000 + rank)
+    mrng = np.random.default_rng(2000)
+    masks = [O.random_valid_mask(spec, mrng, 0.7) for _ in range(spec.n_domain)]
+    log("building model + parameters")
+    model, P = build(spec, dev)
+    log("model ready")
+    model.domain_mask = [[torch.tensor(m, dtype=torch.bool, device=dev) for m in mk] for mk in masks]
+    masks_dev = aread_amd.pack_masks(masks, spec.n_domain, model.edge_num, dev)
+    n_batches = 4
+    batches = []
+    for _ in range(n_batches):
+        x, y = synth.amazon_batch(spec, rng, B, domain=args.domain_dist)
+        batches.append((torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev), x, y))
+    bufs = model.make_step_buffers(B, multi_domain=True, device=dev)
+    xs = torch.empty_like(batches[0][0])
+    ys = torch.empty_like(batches[0][1])
+
+    def step():
+        return model.train_step(xs, ys, bufs, masks_dev=masks_dev, set_grads=False)
+
+    # ---- warm-up (also sizes the embedding-backward workspace) ---------------------------------------
+    xs.copy_(batches[0][0]); ys.copy_(batches[0][1])
+    log("first eager step")
+    step()
+    torch.cuda.synchronize()
+    log("first step done")
+    graph = None
+    if not args.no_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step()
+            torch.cuda.synchronize()
+            log("hipGraph captured")
+        except Exception as exc:                                      # noqa: BLE001
+            if rank == 0:
+                print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); timing eager launches", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+
+    def run_one(i):
+        xb, yb = batches[i % n_batches][:2]
+        xs.copy_(xb, non_blocking=True); ys.copy_(yb, non_blocking=True)
+        if graph is not None:
+            graph.replay()
+        else:
+            step()
+
+    for i in range(args.warmup):
+        run_one(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        run_one(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    loss = float(bufs["total"])
+    log(f"timed region done: {dt / args.steps * 1e3:.3f} ms/step")
+    ms_per_step = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+
+    # ---- roofline of the dominant kernel: the dense-L2 table sweep (read table, write dense gradient) ----
+    roofline = measure_l2_kernel(model, bufs, L)
+    gather = measure_gather_kernel(model, xs, bufs, L)
+
+    out = {
+        "metric": "CTR samples/s fwd+bwd, AREAD 25-domain batch=8192", "value": round(value, 1), "unit": "samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "AREAD HEI+HEMP-mask fwd+bagging BCE+L2+bwd, Amazon-like 25-domain, dims "
+                               "[1368287,7,25,45,11,22356,10], E=32, 17 id columns, experts 4x(256,128,64), towers 3/6/12",
+                   "batch_per_gpu": B, "global_batch": B * world, "domain_dist": args.domain_dist,
+                   "dropout": args.dropout, "mask_active_frac": 0.7, "optimizer_in_timed_region": False,
+                   "dense_table_l2_in_timed_region": True, "launch": "hipGraph replay" if graph is not None else "eager",
+                   "parallelism": f"dp{world}"},
+        "roofline": roofline, "gather_roofline": gather, "loss": round(loss, 6),
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(O, spec, P, masks, batches, args)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _time_kernel(fn, iters=30, warm=3):
+    """Average duration of one launch, HIP events on the stream the kernel is launched on."""
+    st = torch.cuda.current_stream()
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(iters):
+        fn()
+    e1.record(st)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3     # seconds
+
+
+def measure_l2_kernel(model, bufs, L):
+    table = model.embedding.embedding_dict.weight
+    n = table.numel()
+    part = model._l2_partials(table.device)
+    fn = lambda: L.check(L.lib().aread_l2_table(L.ptr(table), n, model.l2_reg_embedding, 1.0, L.ptr(bufs["gtable"]),
+                                                L.ptr(part), L.stream()))
+    t = _time_kernel(fn)
+    alg = 2.0 * n * 4                               # read every weight once, write every gradient once
+    ach = alg / t / 1e9
+    return {"kernel": "k_l2_table", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": alg,
+            "avg_launch_us": round(t * 1e6, 2)}
+
+
+def measure_gather_kernel(model, xs, bufs, L):
+    emb = model.embedding
+    table = emb.embedding_dict.weight
+    B = xs.shape[0]
+    out = torch.empty((B, emb.output_dim0, emb.embed_dim), device=xs.device)
+    off = emb._offsets_dev(xs.device)
+    fn = lambda: L.check(L.lib().aread_embed_fwd(L.ptr(xs), B, xs.shape[1], L.ptr(off), L.ptr(table), table.shape[0],
+                                                 emb.embed_dim, emb.one_hot_field_num, emb.multi_hot_field_num,
+                                                 emb.seq_maxlen, emb._pool, None, B, L.ptr(out), None, L.stream()))
+    t = _time_kernel(fn)
+    per_sample = xs.shape[1] * emb.embed_dim * 4 + xs.shape[1] * 4 + emb.output_dim0 * emb.embed_dim * 4
+    read_stream = xs.shape[1] * emb.embed_dim * 4 + xs.shape[1] * 4
+    ach = per_sample * B / t / 1e9
+    return {"kernel": "k_embed_fwd", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "read_stream_frac": round(read_stream * B / t / 1e9 / HBM_PEAK_GBS, 4),
+            "algorithmic_bytes_per_launch": per_sample * B, "avg_launch_us": round(t * 1e6, 2)}
+
+
+def cpu_baseline(O, spec, P, masks, batches, args):
+    """The CPU oracle (a port of the reference path, pinned to it by tests/golden) on the host cores:
+    the same 25-domain step as 25 per-domain calls + one backward, bounded to a few steps."""
+    n = max(1, args.cpu_steps)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))          # the GPU box gives one GPU a 16-core share; more threads only thrash
+    torch.set_num_threads(cores)
+    log(f"cpu baseline (oracle) on {cores} threads ...")
+    x, y = batches[0][2], batches[0][3]
+    O.step(P, spec, x[:256], y[:256], masks, drop_seed=1)             # warm the allocator / thread pool
+    log("cpu baseline warm-up done")
+    t0 = time.perf_counter()
+    for i in range(n):
+        xb, yb = batches[i % len(batches)][2], batches[i % len(batches)][3]
+        O.step(P, spec, xb, yb, masks, drop_seed=i)
+    dt = time.perf_counter() - t0
+    return {"value": round(n * x.shape[0] / dt, 1), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} full steps of the same workload (B={x.shape[0]}, 25 per-domain calls + one backward each), "
+                      f"{dt:.1f} s of CPU time", "ms_per_step": round(dt / n * 1e3, 1)}
+
+
+if __name__ == "__main__":
+    main()
