@@ -111,7 +111,7 @@ class _RegFn(torch.autograd.Function):
     def forward(ctx, table, dense, model):
         ctx.model = model
         ctx.save_for_backward(table, dense)
-        out = torch.zeros(65, dtype=torch.float32, device=table.device)
+        out = torch.zeros(257, dtype=torch.float32, device=table.device)
         lib = L.lib()
         part = model._l2_partials(table.device)
         L.check(lib.aread_l2_table(L.ptr(table), table.numel(), model.l2_reg_embedding, 1.0, None, L.ptr(part), L.stream()))
@@ -453,7 +453,7 @@ class AREAD(nn.Module):
             de=torch.empty((int(lay.max_rows), self.embed_output_dim), dtype=torch.float32, device=device),
             probs=torch.empty((self.n_heads, B), dtype=torch.float32, device=device),
             loss=torch.zeros(1 + n_seg, dtype=torch.float32, device=device),
-            reg=torch.zeros(65, dtype=torch.float32, device=device),
+            reg=torch.zeros(257, dtype=torch.float32, device=device),
             total=torch.zeros(1, dtype=torch.float32, device=device),
             gdense=torch.zeros_like(self.dense.data),
             gtable=torch.empty_like(self.embedding.embedding_dict.weight.data),

@@ -78,7 +78,7 @@ static int layer_fwd(Ctx& x, const LayerL& L, const LayerWs& lw, const float* in
     f.part = x.ws + lw.part; f.mean = x.ws + lw.mean; f.rstd = x.ws + lw.rstd; f.var = x.ws + lw.var;
     f.rmean = x.c->stats + L.rmean; f.rvar = x.c->stats + L.rvar;
     f.ncols = L.ncols; f.h = L.out_dim; f.train = x.c->train; f.level = level; f.r = x.r; f.mp = x.mp;
-    LAUNCH(k_bn_finalize, dim3(x.c->n_seg, cdiv(L.ncols, 256)), dim3(256), f);
+    LAUNCH(k_bn_finalize, dim3(x.c->n_seg, cdiv(L.ncols, 16)), dim3(256), f);
     BnActP a = {};
     a.H = x.ws + lw.H; a.Act = x.ws + lw.Act; a.mean = f.mean; a.rstd = f.rstd;
     a.gamma = x.params + L.gamma; a.beta = x.params + L.beta;
@@ -107,7 +107,7 @@ static int simple_gemm(Ctx& x, const float* A, int64_t lda, bool a_kc, const flo
 
 template <int MAXV>
 static void launch_rowwise_fwd(Ctx& x, const RowwiseP& p) {
-    hipLaunchKernelGGL((k_rowwise_fwd<MAXV>), dim3(x.n_tiles), dim3(256), 0, x.st, p);
+    hipLaunchKernelGGL((k_rowwise_fwd<MAXV>), dim3(x.n_tiles * SUB), dim3(256), 0, x.st, p);
 }
 
 extern "C" int aread_forward(const aread_model* m, const aread_call* c, const float* e_in, void* stream) {
@@ -164,7 +164,7 @@ extern "C" int aread_forward(const aread_model* m, const aread_call* c, const fl
             ml.prev = ws + x.w.tw[l - 1][Sp.n_layers - 1].Act; ml.In = ws + x.w.In[l];
             ml.n_src = cfg.n_tower[l - 1]; ml.n_t = cfg.n_tower[l]; ml.w = S.L[0].in_dim; ml.level = l; ml.mask_off = m->mask_off[l];
             ml.gate_part = want_gates ? ws + x.w.gate_part : nullptr; ml.r = x.r; ml.mp = x.mp;
-            LAUNCH(k_mixl, dim3(x.n_tiles), dim3(256), ml);
+            LAUNCH(k_mixl, dim3(x.n_tiles * SUB), dim3(256), ml);
         }
         TRY(stack_fwd(x, S, x.w.tw[l], ws + x.w.In[l], l));
     }
@@ -177,20 +177,23 @@ extern "C" int aread_forward(const aread_model* m, const aread_call* c, const fl
     hp.z = ws + x.w.z; hp.prob = ws + x.w.prob; hp.dz = ws + x.w.dz; hp.probs_out = c->probs; hp.B = c->B;
     hp.y = c->y; hp.seg_weight = c->seg_weight; hp.dprobs = nullptr;
     hp.loss_part = (c->y && c->loss_out) ? ws + x.w.loss_part : nullptr; hp.level = LL; hp.r = x.r; hp.mp = x.mp;
-    LAUNCH(k_heads_fwd, dim3(x.n_tiles), dim3(256), hp);
+    LAUNCH(k_heads_fwd, dim3(x.n_tiles * SUB), dim3(256), hp);
     if (hp.loss_part) LAUNCH(k_loss_finish, dim3(1), dim3(64), ws + x.w.loss_part, c->seg_weight, c->loss_out, x.r);
     // 8. running statistics, in domain order
     if (c->train && c->update_running) {
-        auto run = [&](const LayerL& L, const LayerWs& lw, int level) -> int {
-            BnRunP p = {};
+        BnRunAllP all = {};
+        int max_cols = 0;
+        auto add = [&](const LayerL& L, const LayerWs& lw, int level) {
+            BnRunP& p = all.L[all.n_layers++];
             p.mean = ws + lw.mean; p.var = ws + lw.var; p.rmean = c->stats + L.rmean; p.rvar = c->stats + L.rvar;
-            p.nbt = c->nbt + L.nbt0; p.ncols = L.ncols; p.h = L.out_dim; p.level = level; p.r = x.r; p.mp = x.mp;
-            LAUNCH(k_bn_running, dim3(cdiv(L.ncols, 256)), dim3(256), p);
-            return AREAD_OK;
+            p.nbt = c->nbt + L.nbt0; p.ncols = L.ncols; p.h = L.out_dim; p.level = level;
+            if (L.ncols > max_cols) max_cols = L.ncols;
         };
-        for (int j = 0; j < m->experts.n_layers; ++j) TRY(run(m->experts.L[j], x.w.ex[j], -1));
+        for (int j = 0; j < m->experts.n_layers; ++j) add(m->experts.L[j], x.w.ex[j], -1);
         for (int l = 0; l < cfg.n_level; ++l)
-            for (int j = 0; j < m->towers[l].n_layers; ++j) TRY(run(m->towers[l].L[j], x.w.tw[l][j], l));
+            for (int j = 0; j < m->towers[l].n_layers; ++j) add(m->towers[l].L[j], x.w.tw[l][j], l);
+        all.r = x.r; all.mp = x.mp;
+        LAUNCH(k_bn_running, dim3(cdiv(max_cols, 256), all.n_layers), dim3(256), all);
     }
     return AREAD_OK;
 }
@@ -224,16 +227,15 @@ static int layer_bwd(Ctx& x, const LayerL& L, const LayerWs& lw, const float* in
     a.ncols = L.ncols; a.h = L.out_dim; a.level = level; a.stack = L.stack; a.layer = L.layer; a.train = x.c->train;
     a.seed = x.c->drop_seed; a.thr = x.thr; a.keep_scale = x.keep_scale; a.r = x.r; a.mp = x.mp;
     LAUNCH(k_act_bwd, dim3(x.n_tiles, cdiv(L.ncols, 64)), dim3(256), a);
-    BnBwdFinP f = {};
-    f.bpart = ws + lw.bpart; f.s12 = ws + lw.s12; f.dgamma = grads + L.gamma; f.dbeta = grads + L.beta;
-    f.ncols = L.ncols; f.h = L.out_dim; f.level = level; f.r = x.r; f.mp = x.mp;
-    LAUNCH(k_bn_bwd_finalize, dim3(cdiv(L.ncols, 256)), dim3(256), f);
+    LAUNCH(k_seg_reduce, dim3(x.c->n_seg, cdiv(2 * L.ncols, 16)), dim3(256), ws + lw.bpart, (int64_t)2 * L.ncols, 2 * L.ncols,
+           ws + lw.s12, 1, x.r);
     BnBwdApplyP b = {};
     b.d = d; b.H = ws + lw.H; b.mean = ws + lw.mean; b.rstd = ws + lw.rstd; b.gamma = x.params + L.gamma; b.s12 = ws + lw.s12;
+    b.dgamma = grads + L.gamma; b.dbeta = grads + L.beta;
     b.cpart = ws + lw.cpart; b.ncols = L.ncols; b.h = L.out_dim; b.level = level; b.r = x.r; b.mp = x.mp;
     LAUNCH(k_bn_bwd_apply, dim3(x.n_tiles, cdiv(L.ncols, 64)), dim3(256), b);
-    LAUNCH(k_reduce_tiles, dim3(cdiv(L.ncols, 256)), dim3(256), ws + lw.cpart, (int64_t)L.ncols, L.ncols, grads + L.b, L.ncols,
-           (int64_t)0, 0, x.r);
+    LAUNCH(k_reduce_tiles, dim3(cdiv(L.ncols, 16)), dim3(256), ws + lw.cpart, (int64_t)L.ncols, L.ncols, grads + L.b, L.ncols,
+           (int64_t)0, 0, 1, x.r);
     const bool shared = L.in_gs == 0 && L.G > 1;
     const uint8_t* act = (level >= 0 && L.G > 1) ? level_active(x, level) : nullptr;
     // dgrad: d_in = dH W
@@ -256,7 +258,7 @@ static int layer_bwd(Ctx& x, const LayerL& L, const LayerWs& lw, const float* in
 
 template <int NC, int MAXV>
 static void launch_rowwise_bwd2(Ctx& x, const RowwiseBwdP& p) {
-    hipLaunchKernelGGL((k_rowwise_bwd<NC, MAXV>), dim3(x.n_tiles), dim3(256), 0, x.st, p);
+    hipLaunchKernelGGL((k_rowwise_bwd<NC, MAXV>), dim3(x.n_tiles * SUB), dim3(256), 0, x.st, p);
 }
 template <int MAXV>
 static void launch_rowwise_bwd(Ctx& x, const RowwiseBwdP& p) {
@@ -285,7 +287,7 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     HeadsP hp = {};
     hp.prob = ws + x.w.prob; hp.dz = ws + x.w.dz; hp.n_heads = m->n_heads; hp.ld_h = m->ld_h; hp.B = c->B;
     hp.y = c->y; hp.seg_weight = c->seg_weight; hp.dprobs = dprobs; hp.level = LL; hp.r = x.r; hp.mp = x.mp;
-    LAUNCH(k_heads_dz, dim3(x.n_tiles), dim3(256), hp);
+    LAUNCH(k_heads_dz, dim3(x.n_tiles * SUB), dim3(256), hp);
     // 2. heads backward
     const LayerWs& last = x.w.tw[LL][m->towers[LL].n_layers - 1];
     HeadsBwdP hb = {};
@@ -293,9 +295,9 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     hb.n_heads = m->n_heads; hb.ld_h = m->ld_h; hb.dact = ws + last.dAct; hb.dlin = ws + x.w.dlin;
     hb.part = ws + x.w.misc_part; hb.ldp = 1024; hb.r = x.r;
     AR_CHECK_ARG(m->n_heads * m->h_last <= 1024, "aread_backward: n_heads*h_last too large");
-    LAUNCH(k_heads_bwd, dim3(x.n_tiles), dim3(256), hb);
-    LAUNCH(k_reduce_tiles, dim3(cdiv(m->n_heads * m->h_last, 256)), dim3(256), ws + x.w.misc_part, (int64_t)1024,
-           m->n_heads * m->h_last, grads + m->head_w + D, m->h_last, (int64_t)m->head_ld, 0, x.r);
+    LAUNCH(k_heads_bwd, dim3(x.n_tiles * SUB), dim3(256), hb);
+    LAUNCH(k_reduce_tiles, dim3(cdiv(m->n_heads * m->h_last, 16)), dim3(256), ws + x.w.misc_part, (int64_t)1024,
+           m->n_heads * m->h_last, grads + m->head_w + D, m->h_last, (int64_t)m->head_ld, 0, SUB, x.r);
     // dcn = dz V[:, :D]   and   dV[:, :D] = dz^T cn
     TRY(simple_gemm(x, ws + x.w.dz, m->ld_h, true, P + m->head_w, m->head_ld, false, ws + x.w.dcn, D, nullptr, (int)x.rows, D,
                     m->n_heads, 0, 1));
@@ -316,7 +318,7 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
             mb.dprev = ws + x.w.tw[l - 1][Sp.n_layers - 1].dAct;
             mb.n_src = cfg.n_tower[l - 1]; mb.n_t = cfg.n_tower[l]; mb.w = S.L[0].in_dim; mb.level = l; mb.mask_off = m->mask_off[l];
             mb.r = x.r; mb.mp = x.mp;
-            LAUNCH(k_mixl_bwd, dim3(x.n_tiles), dim3(256), mb);
+            LAUNCH(k_mixl_bwd, dim3(x.n_tiles * SUB), dim3(256), mb);
         }
     }
     // 4. MMoE mix backward
@@ -326,7 +328,7 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     m0.glog = ws + x.w.glogE; m0.dglog = ws + x.w.dglogE; m0.ld_g = m->ld_ge; m0.X = ws + x.w.ex[nle - 1].Act;
     m0.dU = ws + x.w.dIn[0]; m0.dX = ws + x.w.ex[nle - 1].dAct; m0.n_t = cfg.n_tower[0]; m0.n_exp = cfg.n_expert; m0.h = EL.out_dim;
     m0.r = x.r; m0.mp = x.mp;
-    LAUNCH(k_mix0_bwd, dim3(x.n_tiles), dim3(256), m0);
+    LAUNCH(k_mix0_bwd, dim3(x.n_tiles * SUB), dim3(256), m0);
     // 5. experts; the first layer writes de_out
     for (int j = nle - 1; j >= 0; --j) {
         const float* in = j == 0 ? e_in : ws + x.w.ex[j - 1].Act;
@@ -338,8 +340,8 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     TRY(simple_gemm(x, ws + x.w.dglogE, m->ld_ge, true, P + m->gate_w, D, false, de_out, D, nullptr, (int)x.rows, D, n_ge, 1, 1));
     TRY(wgrad(x, ws + x.w.dglogE, m->ld_ge, 0, e_in, D, 0, 1, n_ge, D, grads + m->gate_w, D, 0, nullptr));
     LAUNCH(k_colsum, dim3(x.n_tiles), dim3(256), ws + x.w.dglogE, (int64_t)m->ld_ge, n_ge, ws + x.w.misc_part, (int64_t)1024, x.r);
-    LAUNCH(k_reduce_tiles, dim3(cdiv(n_ge, 256)), dim3(256), ws + x.w.misc_part, (int64_t)1024, n_ge, grads + m->gate_b, n_ge,
-           (int64_t)0, 0, x.r);
+    LAUNCH(k_reduce_tiles, dim3(cdiv(n_ge, 16)), dim3(256), ws + x.w.misc_part, (int64_t)1024, n_ge, grads + m->gate_b, n_ge,
+           (int64_t)0, 0, 1, x.r);
     if (m->gate_rows > 0) {
         TRY(simple_gemm(x, ws + x.w.dglogT, m->ld_gt, true, P + m->tgate_w, 2 * E, false, ws + x.w.dq, 2 * E, nullptr, (int)x.rows,
                         2 * E, m->gate_rows, 0, 1));
@@ -347,8 +349,8 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
         AR_CHECK_ARG(m->gate_rows <= 1024, "aread_backward: too many gate rows");
         LAUNCH(k_colsum, dim3(x.n_tiles), dim3(256), ws + x.w.dglogT, (int64_t)m->ld_gt, m->gate_rows, ws + x.w.misc_part,
                (int64_t)1024, x.r);
-        LAUNCH(k_reduce_tiles, dim3(cdiv(m->gate_rows, 256)), dim3(256), ws + x.w.misc_part, (int64_t)1024, m->gate_rows,
-               grads + m->tgate_b, m->gate_rows, (int64_t)0, 0, x.r);
+        LAUNCH(k_reduce_tiles, dim3(cdiv(m->gate_rows, 16)), dim3(256), ws + x.w.misc_part, (int64_t)1024, m->gate_rows,
+               grads + m->tgate_b, m->gate_rows, (int64_t)0, 0, 1, x.r);
     } else {
         AR_HIP(hipMemsetAsync(ws + x.w.dq, 0, (size_t)x.rows * 2 * E * sizeof(float), x.st));
     }
@@ -362,25 +364,26 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     AR_LAUNCH_CHECK();
     const float* rp = ws + x.w.rw_part;
     if (cfg.n_cross > 0) {
-        LAUNCH(k_reduce_tiles, dim3(cdiv(cfg.n_cross * D, 256)), dim3(256), rp, rb.part_ld, cfg.n_cross * D, grads + m->cn_w,
-               cfg.n_cross * D, (int64_t)0, 0, x.r);
-        LAUNCH(k_reduce_tiles, dim3(cdiv(cfg.n_cross * D, 256)), dim3(256), rp + (int64_t)cfg.n_cross * D, rb.part_ld, cfg.n_cross * D,
-               grads + m->cn_b, cfg.n_cross * D, (int64_t)0, 0, x.r);
+        LAUNCH(k_reduce_tiles, dim3(cdiv(cfg.n_cross * D, 16)), dim3(256), rp, rb.part_ld, cfg.n_cross * D, grads + m->cn_w,
+               cfg.n_cross * D, (int64_t)0, 0, SUB, x.r);
+        LAUNCH(k_reduce_tiles, dim3(cdiv(cfg.n_cross * D, 16)), dim3(256), rp + (int64_t)cfg.n_cross * D, rb.part_ld, cfg.n_cross * D,
+               grads + m->cn_b, cfg.n_cross * D, (int64_t)0, 0, SUB, x.r);
     }
-    LAUNCH(k_reduce_tiles, dim3(cdiv(D + 1, 256)), dim3(256), rp + (int64_t)2 * cfg.n_cross * D, rb.part_ld, D, grads + m->lin_w, D,
-           (int64_t)0, 0, x.r);
+    LAUNCH(k_reduce_tiles, dim3(cdiv(D, 16)), dim3(256), rp + (int64_t)2 * cfg.n_cross * D, rb.part_ld, D, grads + m->lin_w, D,
+           (int64_t)0, 0, SUB, x.r);
     LAUNCH(k_reduce_tiles, dim3(1), dim3(256), rp + (int64_t)(2 * cfg.n_cross + 1) * D, rb.part_ld, 1, grads + m->lin_b, 1,
-           (int64_t)0, 0, x.r);
+           (int64_t)0, 0, SUB, x.r);
     // 8. group embedding
-    LAUNCH(k_grp_bwd, dim3(1), dim3(256), ws + x.w.dgrp_part, grads + m->group_emb, cfg.n_tower[0], E, x.r, x.mp);
+    LAUNCH(k_seg_reduce, dim3(c->n_seg, cdiv(E, 16)), dim3(256), ws + x.w.dgrp_part, (int64_t)E, E, ws + x.w.grp, SUB, x.r);
+    LAUNCH(k_grp_bwd, dim3(1), dim3(256), ws + x.w.grp, grads + m->group_emb, cfg.n_tower[0], E, x.r, x.mp);
     return AREAD_OK;
 }
 
 extern "C" int aread_l2_dense(const float* params, const float* coef, int64_t n, float* grads, float* loss_out,
                               int accumulate, void* stream) {
     AR_CHECK_ARG(params && coef && loss_out && n > 0, "aread_l2_dense: bad arguments");
-    // the partial sums live at the tail of loss_out's caller-provided scratch: loss_out[1..64]
-    hipLaunchKernelGGL(k_l2_dense, dim3(64), dim3(256), 0, (hipStream_t)stream, params, coef, n, grads, loss_out + 1);
+    // the partial sums live at the tail of loss_out's caller-provided scratch: loss_out[1..256]
+    hipLaunchKernelGGL(k_l2_dense, dim3(256), dim3(256), 0, (hipStream_t)stream, params, coef, n, grads, loss_out + 1);
     AR_LAUNCH_CHECK();
-    return aread_l2_finish(loss_out + 1, 64, 1.0f, loss_out, accumulate, stream);
+    return aread_l2_finish(loss_out + 1, 256, 1.0f, loss_out, accumulate, stream);
 }

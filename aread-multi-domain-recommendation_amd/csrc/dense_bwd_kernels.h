@@ -6,16 +6,50 @@
 // ------------------------------------------------------------------------------------------------
 // generic reductions
 // ------------------------------------------------------------------------------------------------
-// out[(c / gw) * gs + c % gw] (+)= sum over live tiles of part[tile*ld + c]
+// out[(c / gw) * gs + c % gw] (+)= sum over live partial slots of part[slot*ld + c]
+// A slot covers 64/sub rows (sub partial slots per 64-row tile).  Block = 16 slot-groups x 16 columns; the
+// 16 partial sums of a column are combined through LDS in a fixed order (bitwise reproducible).
 __global__ __launch_bounds__(256) void k_reduce_tiles(const float* part, int64_t ld, int ncols, float* out, int gw,
-                                                      int64_t gs, int accumulate, RowsP r) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= ncols) return;
+                                                      int64_t gs, int accumulate, int sub, RowsP r) {
+    __shared__ float s_acc[16][17];
+    const int cl = threadIdx.x & 15, tg = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     float s = 0.f;
-    for (int t = 0; t < r.n_tiles; ++t)
-        if (r.tile_seg[t] >= 0) s += part[(int64_t)t * ld + c];
-    float* o = out + (int64_t)(c / gw) * gs + (c % gw);
-    *o = accumulate ? *o + s : s;
+    if (c < ncols) {
+        const int n_slots = r.n_tiles * sub;
+        for (int t = tg; t < n_slots; t += 16)
+            if (r.tile_seg[t / sub] >= 0) s += part[(int64_t)t * ld + c];
+    }
+    s_acc[tg][cl] = s;
+    __syncthreads();
+    if (tg == 0 && c < ncols) {
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tot += s_acc[k][cl];
+        float* o = out + (int64_t)(c / gw) * gs + (c % gw);
+        *o = accumulate ? *o + tot : tot;
+    }
+}
+
+// out[seg][c] = sum over the tiles of segment seg of part[tile*ld + c]   (grid: (n_seg, ceil(ncols/16)))
+__global__ __launch_bounds__(256) void k_seg_reduce(const float* part, int64_t ld, int ncols, float* out, int sub, RowsP r) {
+    __shared__ float s_acc[16][17];
+    const int seg = blockIdx.x;
+    const int cl = threadIdx.x & 15, tg = threadIdx.x >> 4;
+    const int c = blockIdx.y * 16 + cl;
+    const int cnt = r.seg_count[seg];
+    const int t0 = (r.seg_start[seg] / TILE_M) * sub, nt = ((cnt + TILE_M - 1) / TILE_M) * sub;
+    float s = 0.f;
+    if (c < ncols)
+        for (int t = tg; t < nt; t += 16) s += part[(int64_t)(t0 + t) * ld + c];
+    s_acc[tg][cl] = s;
+    __syncthreads();
+    if (tg == 0 && c < ncols) {
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tot += s_acc[k][cl];
+        out[(int64_t)seg * ncols + c] = tot;
+    }
 }
 
 // part[tile][c] = sum over the valid rows of the tile of X[row][c]
@@ -55,17 +89,17 @@ struct HeadsBwdP {
 };
 
 __global__ __launch_bounds__(256) void k_heads_bwd(const HeadsBwdP p) {
-    const int tile = blockIdx.x;
+    const int tile = blockIdx.x / SUB, r_lo = (blockIdx.x % SUB) * SUB_ROWS;
     if (p.r.tile_seg[tile] < 0) return;
     const int ncols = p.n_heads * p.h;
-    for (int it = threadIdx.x; it < TILE_M * ncols; it += 256) {
-        const int rr = it / ncols, col = it - rr * ncols;
+    for (int it = threadIdx.x; it < SUB_ROWS * ncols; it += 256) {
+        const int rr = r_lo + it / ncols, col = it % ncols;
         const int i = col / p.h, c = col - i * p.h;
         const int64_t row = (int64_t)tile * TILE_M + rr;
         p.dact[row * ncols + col] = p.dz[row * p.ld_h + i] * p.head_w[(int64_t)i * p.head_ld + p.D + c];
     }
-    for (int rr = threadIdx.x; rr < TILE_M; rr += 256) {
-        const int64_t row = (int64_t)tile * TILE_M + rr;
+    for (int rl = threadIdx.x; rl < SUB_ROWS; rl += 256) {
+        const int64_t row = (int64_t)tile * TILE_M + r_lo + rl;
         float s = 0.f;
         for (int i = 0; i < p.n_heads; ++i) s += p.dz[row * p.ld_h + i];
         p.dlin[row] = s;
@@ -73,11 +107,11 @@ __global__ __launch_bounds__(256) void k_heads_bwd(const HeadsBwdP p) {
     for (int col = threadIdx.x; col < ncols; col += 256) {
         const int i = col / p.h;
         float s = 0.f;
-        for (int rr = 0; rr < TILE_M; ++rr) {
-            const int64_t row = (int64_t)tile * TILE_M + rr;
+        for (int rl = 0; rl < SUB_ROWS; ++rl) {
+            const int64_t row = (int64_t)tile * TILE_M + r_lo + rl;
             s += p.dz[row * p.ld_h + i] * p.act[row * ncols + col];
         }
-        p.part[(int64_t)tile * p.ldp + col] = s;
+        p.part[(int64_t)blockIdx.x * p.ldp + col] = s;
     }
 }
 
@@ -151,40 +185,11 @@ __global__ __launch_bounds__(256) void k_act_bwd(const ActBwdP p) {
     }
 }
 
-// per (segment, column): s1 = sum dyhat, s2 = sum dyhat*xhat;  dgamma = sum_seg s2, dbeta = sum_seg s1
-struct BnBwdFinP {
-    const float* bpart; float* s12; float* dgamma; float* dbeta; int ncols, h, level;
-    RowsP r; ModeP mp;
-};
-
-__global__ __launch_bounds__(256) void k_bn_bwd_finalize(const BnBwdFinP p) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= p.ncols) return;
-    float dg = 0.f, db = 0.f;
-    for (int seg = 0; seg < p.r.n_seg; ++seg) {
-        const int cnt = p.r.seg_count[seg];
-        float t1 = 0.f, t2 = 0.f;
-        bool act = cnt > 0;
-        if (act && p.level >= 0) act = active_level(p.mp, p.level)[seg * MAX_TOWER + c / p.h] != 0;
-        if (act) {
-            const int t0 = p.r.seg_start[seg] / TILE_M, nt = (cnt + TILE_M - 1) / TILE_M;
-            for (int t = 0; t < nt; ++t) {
-                const float* b = p.bpart + ((int64_t)(t0 + t) * p.ncols + c) * 2;
-                t1 += b[0]; t2 += b[1];
-            }
-            if (cnt > 1) { dg += t2; db += t1; }
-        }
-        p.s12[((int64_t)seg * p.ncols + c) * 2] = t1;
-        p.s12[((int64_t)seg * p.ncols + c) * 2 + 1] = t2;
-    }
-    p.dgamma[c] = dg;
-    p.dbeta[c] = db;
-}
-
 // dyhat -> dH (in place): dH = gamma*rstd*(dyhat - s1/n - xhat*s2/n); per-tile column sums of dH (bias grads)
 struct BnBwdApplyP {
     float* d; const float* H; const float* mean; const float* rstd; const float* gamma; const float* s12;
     float* cpart;                       // [n_tiles][ncols]
+    float* dgamma; float* dbeta;        // written by the blocks of tile 0: sum over BN-applied segments of s2 / s1
     int ncols, h, level;
     RowsP r; ModeP mp;
 };
@@ -198,6 +203,17 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const BnBwdApplyP p) {
     const int rg = threadIdx.x >> 4, cq = threadIdx.x & 15;
     const int c = c0 + cq * 4;
     const bool col_ok = c < p.ncols;
+    if (tile == 0 && threadIdx.x < 64 && c0 + threadIdx.x < p.ncols) {       // BatchNorm affine gradients
+        const int cc = c0 + threadIdx.x;
+        float dg = 0.f, db = 0.f;
+        for (int sg = 0; sg < p.r.n_seg; ++sg) {
+            if (p.r.seg_count[sg] <= 1) continue;
+            if (p.level >= 0 && !active_level(p.mp, p.level)[sg * MAX_TOWER + cc / p.h]) continue;
+            db += p.s12[((int64_t)sg * p.ncols + cc) * 2];
+            dg += p.s12[((int64_t)sg * p.ncols + cc) * 2 + 1];
+        }
+        p.dgamma[cc] = dg; p.dbeta[cc] = db;
+    }
     const int cnt = p.r.seg_count[seg];
     bool act = col_ok;
     if (act && p.level >= 0) act = active_level(p.mp, p.level)[seg * MAX_TOWER + c / p.h] != 0;
@@ -253,21 +269,21 @@ struct MixLBwdP {
 };
 
 __global__ __launch_bounds__(256) void k_mixl_bwd(const MixLBwdP p) {
-    __shared__ float s_ah[TILE_M][MAX_TOWER * MAX_TOWER / 2 + 1];
-    const int tile = blockIdx.x;
+    __shared__ float s_ah[SUB_ROWS][MAX_TOWER * MAX_TOWER / 2 + 1];
+    const int tile = blockIdx.x / SUB, r_lo = (blockIdx.x % SUB) * SUB_ROWS;
     const int seg = p.r.tile_seg[tile];
     if (seg < 0) return;
     const int nvalid = p.r.tile_valid[tile];
     const uint8_t* act = active_level(p.mp, p.level) + seg * MAX_TOWER;
     const uint8_t* mk = p.mp.masks ? p.mp.masks + (size_t)p.mp.seg_dom[seg] * p.mp.edge_count + p.mask_off : nullptr;
-    for (int it = threadIdx.x; it < TILE_M * p.n_t; it += 256) {
-        const int rr = it / p.n_t, t = it - rr * p.n_t;
+    for (int it = threadIdx.x; it < SUB_ROWS * p.n_t; it += 256) {
+        const int rl = it / p.n_t, t = it - rl * p.n_t, rr = r_lo + rl;
         const int64_t row = (int64_t)tile * TILE_M + rr;
         const bool on = rr < nvalid && act[t];
         float a[MAX_TOWER], am[MAX_TOWER], ah[MAX_TOWER], dah[MAX_TOWER], S = 1.f;
         float* dgl = p.dglog + row * p.ld_g + p.goff + t * p.n_src;
         if (!on) {
-            for (int s = 0; s < p.n_src; ++s) { dgl[s] = 0.f; s_ah[rr][t * p.n_src + s] = 0.f; }
+            for (int s = 0; s < p.n_src; ++s) { dgl[s] = 0.f; s_ah[rl][t * p.n_src + s] = 0.f; }
             continue;
         }
         gate_weights(p.glog + row * p.ld_g + p.goff + t * p.n_src, p.n_src, mk, p.n_t, t, p.mp.mode, a, am, ah, &S);
@@ -279,7 +295,7 @@ __global__ __launch_bounds__(256) void k_mixl_bwd(const MixLBwdP p) {
             for (int c = 0; c < p.w; ++c) acc += din[c] * src[s * p.w + c];
             dah[s] = acc;
             dot_ah += acc * ah[s];
-            s_ah[rr][t * p.n_src + s] = ah[s];
+            s_ah[rl][t * p.n_src + s] = ah[s];
         }
         float da[MAX_TOWER], dot_a = 0.f;
         for (int s = 0; s < p.n_src; ++s) {
@@ -290,8 +306,8 @@ __global__ __launch_bounds__(256) void k_mixl_bwd(const MixLBwdP p) {
         for (int s = 0; s < p.n_src; ++s) dgl[s] = a[s] * (da[s] - dot_a);
     }
     __syncthreads();
-    for (int it = threadIdx.x; it < TILE_M * p.n_src; it += 256) {
-        const int rr = it / p.n_src, s = it - rr * p.n_src;
+    for (int it = threadIdx.x; it < SUB_ROWS * p.n_src; it += 256) {
+        const int rl = it / p.n_src, s = it - rl * p.n_src, rr = r_lo + rl;
         const int64_t row = (int64_t)tile * TILE_M + rr;
         float* dst = p.dprev + row * (p.n_src * p.w) + s * p.w;
         const float* din = p.dIn + row * (p.n_t * p.w);
@@ -299,7 +315,7 @@ __global__ __launch_bounds__(256) void k_mixl_bwd(const MixLBwdP p) {
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
             if (rr < nvalid)
                 for (int t = 0; t < p.n_t; ++t) {
-                    const float wgt = s_ah[rr][t * p.n_src + s];
+                    const float wgt = s_ah[rl][t * p.n_src + s];
                     if (wgt != 0.f) {
                         const float4 x = *(const float4*)(din + t * p.w + c);
                         o.x += wgt * x.x; o.y += wgt * x.y; o.z += wgt * x.z; o.w += wgt * x.w;
@@ -318,18 +334,18 @@ struct Mix0BwdP {
 };
 
 __global__ __launch_bounds__(256) void k_mix0_bwd(const Mix0BwdP p) {
-    __shared__ float s_pi[TILE_M][MAX_TOWER * 8 + 1];
-    const int tile = blockIdx.x;
+    __shared__ float s_pi[SUB_ROWS][MAX_TOWER * 8 + 1];
+    const int tile = blockIdx.x / SUB, r_lo = (blockIdx.x % SUB) * SUB_ROWS;
     const int seg = p.r.tile_seg[tile];
     if (seg < 0) return;
     const int nvalid = p.r.tile_valid[tile];
     const uint8_t* act = active_level(p.mp, 0) + seg * MAX_TOWER;
-    for (int it = threadIdx.x; it < TILE_M * p.n_t; it += 256) {
-        const int rr = it / p.n_t, t = it - rr * p.n_t;
+    for (int it = threadIdx.x; it < SUB_ROWS * p.n_t; it += 256) {
+        const int rl = it / p.n_t, t = it - rl * p.n_t, rr = r_lo + rl;
         const int64_t row = (int64_t)tile * TILE_M + rr;
         float* dgl = p.dglog + row * p.ld_g + t * p.n_exp;
         if (!(rr < nvalid && act[t])) {
-            for (int k = 0; k < p.n_exp; ++k) { dgl[k] = 0.f; s_pi[rr][t * p.n_exp + k] = 0.f; }
+            for (int k = 0; k < p.n_exp; ++k) { dgl[k] = 0.f; s_pi[rl][t * p.n_exp + k] = 0.f; }
             continue;
         }
         const float* gl = p.glog + row * p.ld_g + t * p.n_exp;
@@ -347,20 +363,20 @@ __global__ __launch_bounds__(256) void k_mix0_bwd(const Mix0BwdP p) {
             for (int c = 0; c < p.h; ++c) acc += du[c] * x[c];
             dpi[k] = acc;
             dot += acc * pi[k];
-            s_pi[rr][t * p.n_exp + k] = pi[k];
+            s_pi[rl][t * p.n_exp + k] = pi[k];
         }
         for (int k = 0; k < p.n_exp; ++k) dgl[k] = pi[k] * (dpi[k] - dot);
     }
     __syncthreads();
     const int h4 = p.h >> 2;
-    for (int it = threadIdx.x; it < TILE_M * p.n_exp * h4; it += 256) {
-        const int rr = it / (p.n_exp * h4), rem = it - rr * (p.n_exp * h4);
+    for (int it = threadIdx.x; it < SUB_ROWS * p.n_exp * h4; it += 256) {
+        const int rl = it / (p.n_exp * h4), rem = it - rl * (p.n_exp * h4), rr = r_lo + rl;
         const int k = rem / h4, c = (rem - k * h4) * 4;
         const int64_t row = (int64_t)tile * TILE_M + rr;
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
         if (rr < nvalid)
             for (int t = 0; t < p.n_t; ++t) {
-                const float wgt = s_pi[rr][t * p.n_exp + k];
+                const float wgt = s_pi[rl][t * p.n_exp + k];
                 if (wgt != 0.f) {
                     const float4 x = *(const float4*)(p.dU + row * (p.n_t * p.h) + t * p.h + c);
                     o.x += wgt * x.x; o.y += wgt * x.y; o.z += wgt * x.z; o.w += wgt * x.w;
@@ -388,9 +404,10 @@ template <int NC, int RW_MAXV>
 __global__ __launch_bounds__(256) void k_rowwise_bwd(const RowwiseBwdP p) {
     __shared__ float4 s_red[4][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tile = blockIdx.x;
+    const int tile = blockIdx.x / SUB, r_lo = (blockIdx.x % SUB) * SUB_ROWS;
     if (p.r.tile_seg[tile] < 0) return;
     const int nvalid = p.r.tile_valid[tile];
+    const int r_hi = (r_lo + SUB_ROWS < nvalid) ? r_lo + SUB_ROWS : nvalid;
     const int d4 = p.D >> 2;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     constexpr int NCA = NC > 0 ? NC : 1;
@@ -402,7 +419,7 @@ __global__ __launch_bounds__(256) void k_rowwise_bwd(const RowwiseBwdP p) {
 #pragma unroll
         for (int i = 0; i < NCA; ++i) { adw[i][v] = zero; adb[i][v] = zero; }
     }
-    for (int rr = wave; rr < nvalid; rr += 4) {
+    for (int rr = r_lo + wave; rr < r_hi; rr += 4) {
         const int64_t row = (int64_t)tile * TILE_M + rr;
         float4 e[RW_MAXV], c[NCA][RW_MAXV], dc[RW_MAXV], de[RW_MAXV];
         const float4* e4 = (const float4*)(p.e + row * p.D);
@@ -480,7 +497,7 @@ __global__ __launch_bounds__(256) void k_rowwise_bwd(const RowwiseBwdP p) {
         }
     }
     // ---- combine the four waves through LDS, vector by vector, and write the tile partial ----------
-    float* out = p.part + (int64_t)tile * p.part_ld;
+    float* out = p.part + (int64_t)blockIdx.x * p.part_ld;
     auto flush = [&](float4 (&acc)[RW_MAXV], int64_t off) {
         for (int v = 0; v < RW_MAXV; ++v) {
             const int ch = lane + 64 * v;
@@ -507,23 +524,20 @@ __global__ __launch_bounds__(256) void k_rowwise_bwd(const RowwiseBwdP p) {
     // group-embedding gradient partial: sum over valid rows of dq[:, E:2E]
     for (int cidx = threadIdx.x; cidx < p.E; cidx += 256) {
         float s = 0.f;
-        for (int rr = 0; rr < nvalid; ++rr) s += p.dq[((int64_t)tile * TILE_M + rr) * 2 * p.E + p.E + cidx];
-        p.dgrp_part[(int64_t)tile * p.E + cidx] = s;
+        for (int rr = r_lo; rr < r_hi; ++rr) s += p.dq[((int64_t)tile * TILE_M + rr) * 2 * p.E + p.E + cidx];
+        p.dgrp_part[(int64_t)blockIdx.x * p.E + cidx] = s;
     }
 }
 
-// group_embedding gradient (autograd of aread.py:226-229)
-__global__ __launch_bounds__(256) void k_grp_bwd(const float* dgrp_part, float* dgroup, int n_t0, int E, RowsP r, ModeP mp) {
+// group_embedding gradient (autograd of aread.py:226-229) from the per-segment sums of dq[:, E:2E]
+__global__ __launch_bounds__(256) void k_grp_bwd(const float* dgrp_seg, float* dgroup, int n_t0, int E, RowsP r, ModeP mp) {
     for (int i = threadIdx.x; i < n_t0 * E; i += 256) {
         const int t = i / E, c = i - t * E;
         float acc = 0.f;
         if (mp.mode == 0)
             for (int seg = 0; seg < r.n_seg; ++seg) {
-                const int cnt = r.seg_count[seg];
-                if (cnt == 0 || !active_level(mp, 0)[seg * MAX_TOWER + t]) continue;
-                const int t0 = r.seg_start[seg] / TILE_M, nt = (cnt + TILE_M - 1) / TILE_M;
-                float s = 0.f;
-                for (int k = 0; k < nt; ++k) s += dgrp_part[(int64_t)(t0 + k) * E + c];
+                if (r.seg_count[seg] == 0 || !active_level(mp, 0)[seg * MAX_TOWER + t]) continue;
+                const float s = dgrp_seg[(int64_t)seg * E + c];
                 const int n0 = mp.n0act[seg];
                 acc += n0 > 1 ? s / (float)n0 : s;
             }
@@ -535,17 +549,23 @@ __global__ __launch_bounds__(256) void k_grp_bwd(const float* dgrp_part, float* 
 // exactly like the reference's sequence of per-domain calls.
 struct BnRunP {
     const float* mean; const float* var; float* rmean; float* rvar; int64_t* nbt; int ncols, h, level;
+};
+#define MAX_BN_LAYERS (AREAD_MAX_LAYER * (AREAD_MAX_LEVEL + 1))
+struct BnRunAllP {
+    int n_layers;
+    BnRunP L[MAX_BN_LAYERS];
     RowsP r; ModeP mp;
 };
-__global__ __launch_bounds__(256) void k_bn_running(const BnRunP p) {
+__global__ __launch_bounds__(256) void k_bn_running(const BnRunAllP a) {
+    const BnRunP& p = a.L[blockIdx.y];
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= p.ncols) return;
     float rm = p.rmean[c], rv = p.rvar[c];
     int n_upd = 0;
-    for (int seg = 0; seg < p.r.n_seg; ++seg) {
-        const int cnt = p.r.seg_count[seg];
+    for (int seg = 0; seg < a.r.n_seg; ++seg) {
+        const int cnt = a.r.seg_count[seg];
         if (cnt <= 1) continue;
-        if (p.level >= 0 && !active_level(p.mp, p.level)[seg * MAX_TOWER + c / p.h]) continue;
+        if (p.level >= 0 && !active_level(a.mp, p.level)[seg * MAX_TOWER + c / p.h]) continue;
         const int64_t o = (int64_t)seg * p.ncols + c;
         rm = (1.0f - BN_MOMENTUM) * rm + BN_MOMENTUM * p.mean[o];
         rv = (1.0f - BN_MOMENTUM) * rv + BN_MOMENTUM * (p.var[o] * ((float)cnt / (float)(cnt - 1)));

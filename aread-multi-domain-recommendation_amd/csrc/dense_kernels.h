@@ -11,6 +11,8 @@
 #define BN_EPS 1e-5f
 #define BN_MOMENTUM 0.1f
 #define GATE_EPS 1e-8f
+#define SUB 4                        // row-local kernels split a 64-row tile into SUB workgroups ...
+#define SUB_ROWS (TILE_M / SUB)      // ... of SUB_ROWS rows; per-workgroup partial sums are indexed by "slot"
 
 struct RowsP {                       // the parts of the row plan a kernel needs
     const int32_t* tile_seg;
@@ -110,12 +112,12 @@ __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
 template <int RW_MAXV>
 __global__ __launch_bounds__(256) void k_rowwise_fwd(const RowwiseP p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tile = blockIdx.x;
+    const int tile = blockIdx.x / SUB, r_lo = (blockIdx.x % SUB) * SUB_ROWS;
     const int seg = p.r.tile_seg[tile];
     if (seg < 0) return;
     const int nvalid = p.r.tile_valid[tile];
     const int d4 = p.D >> 2;
-    for (int rr = wave; rr < TILE_M; rr += 4) {
+    for (int rr = r_lo + wave; rr < r_lo + SUB_ROWS; rr += 4) {
         const int64_t row = (int64_t)tile * TILE_M + rr;
         const bool valid = rr < nvalid;
         float4 e[RW_MAXV], c[RW_MAXV];
@@ -183,32 +185,53 @@ struct BnFinP {
     RowsP r; ModeP mp;
 };
 
+// grid (n_seg, ceil(ncols/16)); block = 16 tile-groups x 16 columns, merged through LDS in fixed order
 __global__ __launch_bounds__(256) void k_bn_finalize(const BnFinP p) {
-    const int seg = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
-    if (c >= p.ncols) return;
+    __shared__ float s_n[16][17], s_m[16][17], s_q[16][17];
+    const int seg = blockIdx.x;
+    const int cl = threadIdx.x & 15, tg = threadIdx.x >> 4;
+    const int c = blockIdx.y * 16 + cl;
+    const bool col_ok = c < p.ncols;
     const int cnt = p.r.seg_count[seg];
-    float mean = 0.f, rstd = 1.f, var = 0.f;
-    bool act = cnt > 0;
+    bool act = cnt > 0 && col_ok;
     if (act && p.level >= 0) act = active_level(p.mp, p.level)[seg * MAX_TOWER + c / p.h] != 0;
+    const bool stats = act && cnt > 1 && p.train;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    if (stats) {
+        const int t0 = p.r.seg_start[seg] / TILE_M, nt = (cnt + TILE_M - 1) / TILE_M;
+        for (int t = tg; t < nt; t += 16) {
+            const float* pp = p.part + ((int64_t)(t0 + t) * p.ncols + c) * 2;
+            const float nb = (float)p.r.tile_valid[t0 + t], mb = pp[0], m2b = pp[1];
+            const float tot = n + nb, delta = mb - mean;
+            mean += delta * (nb / tot);
+            m2 += m2b + delta * delta * (n * nb / tot);
+            n = tot;
+        }
+    }
+    s_n[tg][cl] = n; s_m[tg][cl] = mean; s_q[tg][cl] = m2;
+    __syncthreads();
+    if (tg != 0 || !col_ok) return;
+    float rstd = 1.f, var = 0.f;
+    mean = 0.f;
     if (act && cnt > 1) {
         if (p.train) {
-            const int t0 = p.r.seg_start[seg] / TILE_M, nt = (cnt + TILE_M - 1) / TILE_M;
-            float n = 0.f, m2 = 0.f;
-            for (int t = 0; t < nt; ++t) {
-                const float* pp = p.part + ((int64_t)(t0 + t) * p.ncols + c) * 2;
-                const float nb = (float)p.r.tile_valid[t0 + t], mb = pp[0], m2b = pp[1];
-                const float tot = n + nb, delta = mb - mean;
-                mean += delta * (nb / tot);
-                m2 += m2b + delta * delta * (n * nb / tot);
-                n = tot;
+            n = 0.f; m2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float nb = s_n[k][cl];
+                if (nb > 0.f) {
+                    const float tot = n + nb, delta = s_m[k][cl] - mean;
+                    mean += delta * (nb / tot);
+                    m2 += s_q[k][cl] + delta * delta * (n * nb / tot);
+                    n = tot;
+                }
             }
             var = m2 / (float)cnt;
-            rstd = 1.0f / sqrtf(var + BN_EPS);
         } else {
             mean = p.rmean[c];
             var = p.rvar[c];
-            rstd = 1.0f / sqrtf(var + BN_EPS);
         }
+        rstd = 1.0f / sqrtf(var + BN_EPS);
     }
     const int64_t o = (int64_t)seg * p.ncols + c;
     p.mean[o] = mean; p.rstd[o] = rstd; p.var[o] = var;
@@ -304,7 +327,7 @@ struct MixLP {
     const float* glog; int ld_g, goff;        // gate logits of this level start at column goff
     const float* prev; float* In;             // prev: [rows][n_src*w]  In: [rows][n_t*w]
     int n_src, n_t, w, level, mask_off;
-    float* gate_part;                          // nullable: [n_tiles][ld_g] per-tile sums of gate*mask
+    float* gate_part;                          // nullable: [n_tiles*SUB][ld_g] per-slot sums of gate*mask
     RowsP r; ModeP mp;
 };
 
@@ -325,24 +348,24 @@ __device__ __forceinline__ void gate_weights(const float* gl, int n_src, const u
 }
 
 __global__ __launch_bounds__(256) void k_mixl(const MixLP p) {
-    // block = one 64-row tile; threads loop over (row, t) pairs
-    __shared__ float s_gate[TILE_M][MAX_TOWER * MAX_TOWER / 2 + 1];
-    const int tile = blockIdx.x;
+    // block = SUB_ROWS rows of one tile; threads loop over (row, t) pairs
+    __shared__ float s_gate[SUB_ROWS][MAX_TOWER * MAX_TOWER / 2 + 1];
+    const int tile = blockIdx.x / SUB, r_lo = (blockIdx.x % SUB) * SUB_ROWS;
     const int seg = p.r.tile_seg[tile];
     if (seg < 0) return;
     const int nvalid = p.r.tile_valid[tile];
     const uint8_t* act = active_level(p.mp, p.level) + seg * MAX_TOWER;
     const uint8_t* mk = p.mp.masks ? p.mp.masks + (size_t)p.mp.seg_dom[seg] * p.mp.edge_count + p.mask_off : nullptr;
     const int ngate = p.n_t * p.n_src;
-    for (int it = threadIdx.x; it < TILE_M * p.n_t; it += 256) {
-        const int rr = it / p.n_t, t = it - rr * p.n_t;
+    for (int it = threadIdx.x; it < SUB_ROWS * p.n_t; it += 256) {
+        const int rl = it / p.n_t, t = it - rl * p.n_t, rr = r_lo + rl;
         const int64_t row = (int64_t)tile * TILE_M + rr;
         float* dst = p.In + row * (p.n_t * p.w) + t * p.w;
         const bool on = rr < nvalid && act[t];
         float a[MAX_TOWER], am[MAX_TOWER], ah[MAX_TOWER], S;
         if (on) gate_weights(p.glog + row * p.ld_g + p.goff + t * p.n_src, p.n_src, mk, p.n_t, t, p.mp.mode, a, am, ah, &S);
         if (p.gate_part && ngate <= MAX_TOWER * MAX_TOWER / 2)
-            for (int s = 0; s < p.n_src; ++s) s_gate[rr][t * p.n_src + s] = on ? am[s] : 0.f;
+            for (int s = 0; s < p.n_src; ++s) s_gate[rl][t * p.n_src + s] = on ? am[s] : 0.f;
         const float* src = p.prev + row * (p.n_src * p.w);
         for (int c = 0; c < p.w; c += 4) {
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -358,8 +381,8 @@ __global__ __launch_bounds__(256) void k_mixl(const MixLP p) {
         __syncthreads();
         for (int gcol = threadIdx.x; gcol < ngate; gcol += 256) {
             float s = 0.f;
-            for (int rr = 0; rr < TILE_M; ++rr) s += s_gate[rr][gcol];
-            p.gate_part[(int64_t)tile * p.ld_g + p.goff + gcol] = s;
+            for (int rl = 0; rl < SUB_ROWS; ++rl) s += s_gate[rl][gcol];
+            p.gate_part[(int64_t)blockIdx.x * p.ld_g + p.goff + gcol] = s;
         }
     }
 }
@@ -371,7 +394,7 @@ __global__ __launch_bounds__(256) void k_gate_stats(const float* gate_part, int 
     const int t0 = r.seg_start[seg] / TILE_M, nt = (cnt + TILE_M - 1) / TILE_M;
     for (int c = threadIdx.x; c < gate_rows; c += 256) {
         float s = 0.f;
-        for (int t = 0; t < nt; ++t) s += gate_part[(int64_t)(t0 + t) * ld_g + c];
+        for (int t = 0; t < nt * SUB; ++t) s += gate_part[(int64_t)(t0 * SUB + t) * ld_g + c];
         out[(int64_t)seg * gate_rows + c] = cnt > 0 ? s / (float)cnt : 0.f;
     }
 }
@@ -389,7 +412,7 @@ struct HeadsP {
 
 __global__ __launch_bounds__(256) void k_heads_fwd(const HeadsP p) {
     __shared__ float s_loss[256];
-    const int tile = blockIdx.x;
+    const int tile = blockIdx.x / SUB, r_lo = (blockIdx.x % SUB) * SUB_ROWS;
     const int seg = p.r.tile_seg[tile];
     if (seg < 0) return;
     const int nvalid = p.r.tile_valid[tile];
@@ -397,8 +420,8 @@ __global__ __launch_bounds__(256) void k_heads_fwd(const HeadsP p) {
     const float cnt = (float)p.r.seg_count[seg];
     const float kact = (float)p.mp.kact[seg];
     float loss = 0.f;
-    for (int it = threadIdx.x; it < TILE_M * p.n_heads; it += 256) {
-        const int rr = it / p.n_heads, i = it - rr * p.n_heads;
+    for (int it = threadIdx.x; it < SUB_ROWS * p.n_heads; it += 256) {
+        const int rr = r_lo + it / p.n_heads, i = it % p.n_heads;
         const int64_t row = (int64_t)tile * TILE_M + rr;
         const bool on = rr < nvalid && act[i];
         float z = 0.f, pr = 0.f, dz = 0.f;
@@ -427,7 +450,7 @@ __global__ __launch_bounds__(256) void k_heads_fwd(const HeadsP p) {
             if (threadIdx.x < o) s_loss[threadIdx.x] += s_loss[threadIdx.x + o];
             __syncthreads();
         }
-        if (threadIdx.x == 0) p.loss_part[tile] = s_loss[0];
+        if (threadIdx.x == 0) p.loss_part[blockIdx.x] = s_loss[0];
     }
 }
 
@@ -439,7 +462,7 @@ __global__ __launch_bounds__(64) void k_loss_finish(const float* loss_part, cons
     if (seg < r.n_seg) {
         const int cnt = r.seg_count[seg];
         const int t0 = r.seg_start[seg] / TILE_M, nt = (cnt + TILE_M - 1) / TILE_M;
-        for (int t = 0; t < nt; ++t) bag += loss_part[t0 + t];
+        for (int t = 0; t < nt * SUB; ++t) bag += loss_part[t0 * SUB + t];
         loss_out[1 + seg] = bag;
         bag *= seg_weight ? seg_weight[seg] : 1.f;
     }
@@ -454,15 +477,15 @@ __global__ __launch_bounds__(64) void k_loss_finish(const float* loss_part, cons
 
 // dz = dL/dz for every (row, head): from labels (fused loss) or from an external dL/dprobs.
 __global__ __launch_bounds__(256) void k_heads_dz(const HeadsP p) {
-    const int tile = blockIdx.x;
+    const int tile = blockIdx.x / SUB, r_lo = (blockIdx.x % SUB) * SUB_ROWS;
     const int seg = p.r.tile_seg[tile];
     if (seg < 0) return;
     const int nvalid = p.r.tile_valid[tile];
     const uint8_t* act = active_level(p.mp, p.level) + seg * MAX_TOWER;
     const float cnt = (float)p.r.seg_count[seg], kact = (float)p.mp.kact[seg];
     const float wseg = p.seg_weight ? p.seg_weight[seg] : 1.f;
-    for (int it = threadIdx.x; it < TILE_M * p.ld_h; it += 256) {
-        const int rr = it / p.ld_h, i = it - rr * p.ld_h;
+    for (int it = threadIdx.x; it < SUB_ROWS * p.ld_h; it += 256) {
+        const int rr = r_lo + it / p.ld_h, i = it % p.ld_h;
         const int64_t row = (int64_t)tile * TILE_M + rr;
         float dz = 0.f;
         if (i < p.n_heads && rr < nvalid && act[i]) {

@@ -212,7 +212,7 @@ void ws_layout(const aread_model* m, int64_t B, int n_seg, WsLayout* w) {
     w->prob = take(&o, rows * m->ld_h);
     w->dz = take(&o, rows * m->ld_h);
     w->grp = take(&o, (int64_t)MAX_SEG * E);
-    w->dgrp_part = take(&o, tiles * E);
+    w->dgrp_part = take(&o, tiles * 4 * E);          // SUB slots per tile
     for (int l = 0; l < c.n_level; ++l) {
         const LayerL& L0 = m->towers[l].L[0];
         w->In[l] = take(&o, rows * L0.G * L0.in_dim);
@@ -224,8 +224,8 @@ void ws_layout(const aread_model* m, int64_t B, int n_seg, WsLayout* w) {
     w->active = take(&o, (int64_t)AREAD_MAX_LEVEL * MAX_SEG * MAX_TOWER / 4);
     w->kact = take(&o, 2 * MAX_SEG);      // kact[MAX_SEG] then n0act[MAX_SEG]
     w->seg_dom = take(&o, MAX_SEG);
-    w->loss_part = take(&o, tiles);
-    w->gate_part = take(&o, tiles * m->ld_gt);
+    w->loss_part = take(&o, tiles * 4);
+    w->gate_part = take(&o, tiles * 4 * m->ld_gt);
     // split-K slabs of the largest wgrad
     const int ksplit = (int)((rows + WGRAD_KCHUNK - 1) / WGRAD_KCHUNK);
     int64_t slab = 0;
@@ -237,8 +237,8 @@ void ws_layout(const aread_model* m, int64_t B, int n_seg, WsLayout* w) {
     upd(1, c.n_tower[0] * c.n_expert, D);
     upd(1, m->gate_rows, 2 * E);
     w->slab = take(&o, slab * ksplit);
-    w->rw_part = take(&o, tiles * (int64_t)(2 * MAX_CROSS + 1) * D + tiles * 4);
-    w->misc_part = take(&o, tiles * 1024);
+    w->rw_part = take(&o, tiles * 4 * ((int64_t)(2 * MAX_CROSS + 1) * D + 4));
+    w->misc_part = take(&o, tiles * 4 * 1024);
     w->total = o;
 }
 

@@ -194,7 +194,7 @@ int aread_backward(const aread_model* m, const aread_call* call_host, const floa
                    float* grads, float* de_out, void* stream);
 /* Dense L2 terms: loss_out[0] (+)= sum_i coef[i]*w[i]^2, grads[i] += 2*coef[i]*w[i] (grads may be NULL).
  * coef: device vector like params (aread_model_l2_coef fills a host copy).
- * loss_out must have room for 65 floats: [0] is the result, [1..64] is scratch for block partials. */
+ * loss_out must have room for 257 floats: [0] is the result, [1..256] is scratch for block partials. */
 int aread_model_l2_coef(const aread_model* m, float* coef_host);
 /* Test/debug introspection: float offset of a named workspace buffer (e.g. "cn", "ex0.H", "tw1.0.Act"), -1 if unknown. */
 int64_t aread_debug_ws_offset(const aread_model* m, int64_t B, int n_seg, const char* name);
