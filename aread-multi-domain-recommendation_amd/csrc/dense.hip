@@ -4,7 +4,6 @@
 #include "dense_bwd_kernels.h"
 #include "gemm.h"
 
-#define WGRAD_KCHUNK 1024
 
 struct Ctx {
     const aread_model* m;
@@ -19,6 +18,8 @@ struct Ctx {
     uint32_t thr;
     float keep_scale;
     const float* params;
+    SplitKAllP splitk;      // wgrads waiting for the batched split-K reduction
+    BiasAllP bias;          // layers waiting for the batched bias-gradient reduction
 };
 
 static int make_ctx(const aread_model* m, const aread_call* c, void* stream, Ctx* x) {
@@ -36,7 +37,7 @@ static int make_ctx(const aread_model* m, const aread_call* c, void* stream, Ctx
     x->n_tiles = (int)x->w.n_tiles;
     const PlanView pv = plan_view(c->plan, c->B, c->n_seg);
     x->r.tile_seg = pv.tile_seg; x->r.tile_valid = pv.tile_valid; x->r.row_sample = pv.row_sample;
-    x->r.seg_count = pv.seg_count; x->r.seg_start = pv.seg_start; x->r.n_tiles = x->n_tiles; x->r.n_seg = c->n_seg;
+    x->r.seg_count = pv.seg_count; x->r.seg_start = pv.seg_start; x->r.hdr = pv.hdr; x->r.n_tiles = x->n_tiles; x->r.n_seg = c->n_seg;
     int32_t* ints = (int32_t*)(x->ws + x->w.kact);
     x->mp.active = (const uint8_t*)(x->ws + x->w.active);
     x->mp.kact = ints; x->mp.n0act = ints + MAX_SEG; x->mp.seg_dom = (int32_t*)(x->ws + x->w.seg_dom);
@@ -46,6 +47,8 @@ static int make_ctx(const aread_model* m, const aread_call* c, void* stream, Ctx
     x->thr = drop ? drop_threshold(m->cfg.dropout) : 0u;
     x->keep_scale = drop ? 1.0f / (1.0f - m->cfg.dropout) : 1.f;
     x->params = c->params;
+    x->splitk.n = 0;
+    x->bias.n = 0;
     return AREAD_OK;
 }
 
@@ -202,23 +205,47 @@ extern "C" int aread_forward(const aread_model* m, const aread_call* c, const fl
 // backward
 // ================================================================================================
 static int wgrad(Ctx& x, const float* dY, int64_t ld_dy, int64_t dy_gs, const float* X, int64_t ldx, int64_t x_gs, int G,
-                 int M, int N, float* out, int64_t ldo, int64_t o_gs, const uint8_t* active) {
-    const int ksplit = cdiv(x.rows, WGRAD_KCHUNK);
+                 int M, int N, float* out, int64_t ldo, int64_t o_gs, const uint8_t* active, int64_t slab_off) {
+    const KSplit ks = wgrad_ksplit(x.rows, G, M, N);
     GemmP g = {};
     g.A = dY; g.lda = ld_dy; g.a_gs = dy_gs;
     g.B = X; g.ldb = ldx; g.b_gs = x_gs;
-    g.C = x.ws + x.w.slab; g.ldc = N; g.c_gs = (int64_t)M * N; g.c_ks = (int64_t)G * M * N;
+    g.C = x.ws + slab_off; g.ldc = N; g.c_gs = (int64_t)M * N; g.c_ks = (int64_t)G * M * N;
     g.M = M; g.N = N; g.K = (int)x.rows; g.G = G;
-    g.k_split = ksplit; g.k_chunk = WGRAD_KCHUNK;
+    g.k_split = ks.k_split; g.k_chunk = ks.k_chunk;
     g.gate_axis = 2; g.tile_seg = x.r.tile_seg; g.tile_valid = x.r.tile_valid; g.active = active; g.active_ld = MAX_TOWER;
     TRY(launch_gemm(g, false, false, x.st));
-    LAUNCH(k_splitk_reduce, dim3(cdiv((int64_t)G * M * N, 256)), dim3(256), x.ws + x.w.slab, ksplit, G, M, N, out, ldo, o_gs, 0);
+    AR_CHECK_ARG(x.splitk.n < MAX_WGRADS, "too many wgrads");
+    SplitKOne& d = x.splitk.d[x.splitk.n++];
+    d.slab = x.ws + slab_off; d.out = out; d.k_split = ks.k_split; d.G = G; d.M = M; d.N = N; d.ldo = ldo; d.o_gs = o_gs;
+    return AREAD_OK;
+}
+
+static int flush_reductions(Ctx& x) {
+    if (x.splitk.n > 0) {
+        int64_t mx = 0;
+        for (int i = 0; i < x.splitk.n; ++i) {
+            const int64_t e = (int64_t)x.splitk.d[i].G * x.splitk.d[i].M * x.splitk.d[i].N;
+            if (e > mx) mx = e;
+        }
+        int bx = cdiv(mx, 64);
+        if (bx > 2048) bx = 2048;
+        LAUNCH(k_splitk_reduce_all, dim3(bx, x.splitk.n), dim3(256), x.splitk);
+        x.splitk.n = 0;
+    }
+    if (x.bias.n > 0) {
+        int mx = 0;
+        for (int i = 0; i < x.bias.n; ++i) if (x.bias.d[i].ncols > mx) mx = x.bias.d[i].ncols;
+        x.bias.r = x.r; x.bias.mp = x.mp;
+        LAUNCH(k_bias_reduce_all, dim3(cdiv(mx, 16), x.bias.n), dim3(256), x.bias);
+        x.bias.n = 0;
+    }
     return AREAD_OK;
 }
 
 // one MLP layer backward.  d = dL/dAct on entry (in lw.dAct); on exit it holds dL/dH.
 static int layer_bwd(Ctx& x, const LayerL& L, const LayerWs& lw, const float* in, float* d_in, int accumulate_d_in,
-                     float* grads, int level) {
+                     float* grads, int level, int64_t slab_off) {
     float* ws = x.ws;
     float* d = ws + lw.dAct;
     ActBwdP a = {};
@@ -227,15 +254,14 @@ static int layer_bwd(Ctx& x, const LayerL& L, const LayerWs& lw, const float* in
     a.ncols = L.ncols; a.h = L.out_dim; a.level = level; a.stack = L.stack; a.layer = L.layer; a.train = x.c->train;
     a.seed = x.c->drop_seed; a.thr = x.thr; a.keep_scale = x.keep_scale; a.r = x.r; a.mp = x.mp;
     LAUNCH(k_act_bwd, dim3(x.n_tiles, cdiv(L.ncols, 64)), dim3(256), a);
-    LAUNCH(k_seg_reduce, dim3(x.c->n_seg, cdiv(2 * L.ncols, 16)), dim3(256), ws + lw.bpart, (int64_t)2 * L.ncols, 2 * L.ncols,
-           ws + lw.s12, 1, x.r);
     BnBwdApplyP b = {};
-    b.d = d; b.H = ws + lw.H; b.mean = ws + lw.mean; b.rstd = ws + lw.rstd; b.gamma = x.params + L.gamma; b.s12 = ws + lw.s12;
-    b.dgamma = grads + L.gamma; b.dbeta = grads + L.beta;
+    b.d = d; b.H = ws + lw.H; b.mean = ws + lw.mean; b.rstd = ws + lw.rstd; b.gamma = x.params + L.gamma; b.bpart = ws + lw.bpart;
     b.cpart = ws + lw.cpart; b.ncols = L.ncols; b.h = L.out_dim; b.level = level; b.r = x.r; b.mp = x.mp;
     LAUNCH(k_bn_bwd_apply, dim3(x.n_tiles, cdiv(L.ncols, 64)), dim3(256), b);
-    LAUNCH(k_reduce_tiles, dim3(cdiv(L.ncols, 16)), dim3(256), ws + lw.cpart, (int64_t)L.ncols, L.ncols, grads + L.b, L.ncols,
-           (int64_t)0, 0, 1, x.r);
+    AR_CHECK_ARG(x.bias.n < MAX_BN_LAYERS_DECL, "too many layers");
+    BiasOne& bo = x.bias.d[x.bias.n++];
+    bo.cpart = ws + lw.cpart; bo.bpart = ws + lw.bpart; bo.db = grads + L.b; bo.dgamma = grads + L.gamma; bo.dbeta = grads + L.beta;
+    bo.ncols = L.ncols; bo.h = L.out_dim; bo.level = level;
     const bool shared = L.in_gs == 0 && L.G > 1;
     const uint8_t* act = (level >= 0 && L.G > 1) ? level_active(x, level) : nullptr;
     // dgrad: d_in = dH W
@@ -250,9 +276,9 @@ static int layer_bwd(Ctx& x, const LayerL& L, const LayerWs& lw, const float* in
         TRY(launch_gemm(g, true, false, x.st));   // inactive towers contribute dH = 0
     }
     // wgrad: dW = dH^T in
-    if (shared) TRY(wgrad(x, d, L.ncols, 0, in, L.in_ld, 0, 1, L.ncols, L.in_dim, grads + L.w, L.in_dim, 0, nullptr));
+    if (shared) TRY(wgrad(x, d, L.ncols, 0, in, L.in_ld, 0, 1, L.ncols, L.in_dim, grads + L.w, L.in_dim, 0, nullptr, slab_off));
     else TRY(wgrad(x, d, L.ncols, L.out_dim, in, L.in_ld, L.in_gs, L.G, L.out_dim, L.in_dim, grads + L.w, L.in_dim,
-                   (int64_t)L.out_dim * L.in_dim, act));
+                   (int64_t)L.out_dim * L.in_dim, act, slab_off));
     return AREAD_OK;
 }
 
@@ -296,19 +322,19 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     hb.part = ws + x.w.misc_part; hb.ldp = 1024; hb.r = x.r;
     AR_CHECK_ARG(m->n_heads * m->h_last <= 1024, "aread_backward: n_heads*h_last too large");
     LAUNCH(k_heads_bwd, dim3(x.n_tiles * SUB), dim3(256), hb);
-    LAUNCH(k_reduce_tiles, dim3(cdiv(m->n_heads * m->h_last, 16)), dim3(256), ws + x.w.misc_part, (int64_t)1024,
+    LAUNCH(k_reduce_tiles, dim3(cdiv(m->n_heads * m->h_last, 32)), dim3(256), ws + x.w.misc_part, (int64_t)1024,
            m->n_heads * m->h_last, grads + m->head_w + D, m->h_last, (int64_t)m->head_ld, 0, SUB, x.r);
     // dcn = dz V[:, :D]   and   dV[:, :D] = dz^T cn
     TRY(simple_gemm(x, ws + x.w.dz, m->ld_h, true, P + m->head_w, m->head_ld, false, ws + x.w.dcn, D, nullptr, (int)x.rows, D,
                     m->n_heads, 0, 1));
-    TRY(wgrad(x, ws + x.w.dz, m->ld_h, 0, ws + x.w.cn, D, 0, 1, m->n_heads, D, grads + m->head_w, m->head_ld, 0, nullptr));
+    TRY(wgrad(x, ws + x.w.dz, m->ld_h, 0, ws + x.w.cn, D, 0, 1, m->n_heads, D, grads + m->head_w, m->head_ld, 0, nullptr, x.w.slab_head));
     // 3. tower pyramid, top down
     for (int l = LL; l >= 0; --l) {
         const StackL& S = m->towers[l];
         for (int j = S.n_layers - 1; j >= 0; --j) {
             const float* in = j == 0 ? ws + x.w.In[l] : ws + x.w.tw[l][j - 1].Act;
             float* d_in = j == 0 ? ws + x.w.dIn[l] : ws + x.w.tw[l][j - 1].dAct;
-            TRY(layer_bwd(x, S.L[j], x.w.tw[l][j], in, d_in, 0, grads, l));
+            TRY(layer_bwd(x, S.L[j], x.w.tw[l][j], in, d_in, 0, grads, l, x.w.slab_tw[l][j]));
         }
         if (l > 0) {
             const StackL& Sp = m->towers[l - 1];
@@ -333,23 +359,24 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     for (int j = nle - 1; j >= 0; --j) {
         const float* in = j == 0 ? e_in : ws + x.w.ex[j - 1].Act;
         float* d_in = j == 0 ? de_out : ws + x.w.ex[j - 1].dAct;
-        TRY(layer_bwd(x, m->experts.L[j], x.w.ex[j], in, d_in, 0, grads, -1));
+        TRY(layer_bwd(x, m->experts.L[j], x.w.ex[j], in, d_in, 0, grads, -1, x.w.slab_ex[j]));
     }
     // 6. gates
     const int n_ge = cfg.n_tower[0] * cfg.n_expert;
     TRY(simple_gemm(x, ws + x.w.dglogE, m->ld_ge, true, P + m->gate_w, D, false, de_out, D, nullptr, (int)x.rows, D, n_ge, 1, 1));
-    TRY(wgrad(x, ws + x.w.dglogE, m->ld_ge, 0, e_in, D, 0, 1, n_ge, D, grads + m->gate_w, D, 0, nullptr));
+    TRY(wgrad(x, ws + x.w.dglogE, m->ld_ge, 0, e_in, D, 0, 1, n_ge, D, grads + m->gate_w, D, 0, nullptr, x.w.slab_gate));
     LAUNCH(k_colsum, dim3(x.n_tiles), dim3(256), ws + x.w.dglogE, (int64_t)m->ld_ge, n_ge, ws + x.w.misc_part, (int64_t)1024, x.r);
-    LAUNCH(k_reduce_tiles, dim3(cdiv(n_ge, 16)), dim3(256), ws + x.w.misc_part, (int64_t)1024, n_ge, grads + m->gate_b, n_ge,
+    LAUNCH(k_reduce_tiles, dim3(cdiv(n_ge, 32)), dim3(256), ws + x.w.misc_part, (int64_t)1024, n_ge, grads + m->gate_b, n_ge,
            (int64_t)0, 0, 1, x.r);
     if (m->gate_rows > 0) {
         TRY(simple_gemm(x, ws + x.w.dglogT, m->ld_gt, true, P + m->tgate_w, 2 * E, false, ws + x.w.dq, 2 * E, nullptr, (int)x.rows,
                         2 * E, m->gate_rows, 0, 1));
-        TRY(wgrad(x, ws + x.w.dglogT, m->ld_gt, 0, ws + x.w.q, 2 * E, 0, 1, m->gate_rows, 2 * E, grads + m->tgate_w, 2 * E, 0, nullptr));
+        TRY(wgrad(x, ws + x.w.dglogT, m->ld_gt, 0, ws + x.w.q, 2 * E, 0, 1, m->gate_rows, 2 * E, grads + m->tgate_w, 2 * E, 0, nullptr,
+                  x.w.slab_tgate));
         AR_CHECK_ARG(m->gate_rows <= 1024, "aread_backward: too many gate rows");
         LAUNCH(k_colsum, dim3(x.n_tiles), dim3(256), ws + x.w.dglogT, (int64_t)m->ld_gt, m->gate_rows, ws + x.w.misc_part,
                (int64_t)1024, x.r);
-        LAUNCH(k_reduce_tiles, dim3(cdiv(m->gate_rows, 16)), dim3(256), ws + x.w.misc_part, (int64_t)1024, m->gate_rows,
+        LAUNCH(k_reduce_tiles, dim3(cdiv(m->gate_rows, 32)), dim3(256), ws + x.w.misc_part, (int64_t)1024, m->gate_rows,
                grads + m->tgate_b, m->gate_rows, (int64_t)0, 0, 1, x.r);
     } else {
         AR_HIP(hipMemsetAsync(ws + x.w.dq, 0, (size_t)x.rows * 2 * E * sizeof(float), x.st));
@@ -364,18 +391,20 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     AR_LAUNCH_CHECK();
     const float* rp = ws + x.w.rw_part;
     if (cfg.n_cross > 0) {
-        LAUNCH(k_reduce_tiles, dim3(cdiv(cfg.n_cross * D, 16)), dim3(256), rp, rb.part_ld, cfg.n_cross * D, grads + m->cn_w,
+        LAUNCH(k_reduce_tiles, dim3(cdiv(cfg.n_cross * D, 32)), dim3(256), rp, rb.part_ld, cfg.n_cross * D, grads + m->cn_w,
                cfg.n_cross * D, (int64_t)0, 0, SUB, x.r);
-        LAUNCH(k_reduce_tiles, dim3(cdiv(cfg.n_cross * D, 16)), dim3(256), rp + (int64_t)cfg.n_cross * D, rb.part_ld, cfg.n_cross * D,
+        LAUNCH(k_reduce_tiles, dim3(cdiv(cfg.n_cross * D, 32)), dim3(256), rp + (int64_t)cfg.n_cross * D, rb.part_ld, cfg.n_cross * D,
                grads + m->cn_b, cfg.n_cross * D, (int64_t)0, 0, SUB, x.r);
     }
-    LAUNCH(k_reduce_tiles, dim3(cdiv(D, 16)), dim3(256), rp + (int64_t)2 * cfg.n_cross * D, rb.part_ld, D, grads + m->lin_w, D,
+    LAUNCH(k_reduce_tiles, dim3(cdiv(D, 32)), dim3(256), rp + (int64_t)2 * cfg.n_cross * D, rb.part_ld, D, grads + m->lin_w, D,
            (int64_t)0, 0, SUB, x.r);
     LAUNCH(k_reduce_tiles, dim3(1), dim3(256), rp + (int64_t)(2 * cfg.n_cross + 1) * D, rb.part_ld, 1, grads + m->lin_b, 1,
            (int64_t)0, 0, SUB, x.r);
     // 8. group embedding
     LAUNCH(k_seg_reduce, dim3(c->n_seg, cdiv(E, 16)), dim3(256), ws + x.w.dgrp_part, (int64_t)E, E, ws + x.w.grp, SUB, x.r);
     LAUNCH(k_grp_bwd, dim3(1), dim3(256), ws + x.w.grp, grads + m->group_emb, cfg.n_tower[0], E, x.r, x.mp);
+    // 9. batched split-K and bias reductions of every layer
+    TRY(flush_reductions(x));
     return AREAD_OK;
 }
 

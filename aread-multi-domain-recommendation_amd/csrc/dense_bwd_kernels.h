@@ -2,30 +2,31 @@
 // per-tile partial sums into parameter gradients in a fixed order (bitwise reproducible, no float atomics).
 #pragma once
 #include "dense_kernels.h"
+#define MAX_BN_LAYERS_DECL (AREAD_MAX_LAYER * (AREAD_MAX_LEVEL + 1))
 
 // ------------------------------------------------------------------------------------------------
 // generic reductions
 // ------------------------------------------------------------------------------------------------
 // out[(c / gw) * gs + c % gw] (+)= sum over live partial slots of part[slot*ld + c]
-// A slot covers 64/sub rows (sub partial slots per 64-row tile).  Block = 16 slot-groups x 16 columns; the
-// 16 partial sums of a column are combined through LDS in a fixed order (bitwise reproducible).
+// A slot covers 64/sub rows (sub partial slots per 64-row tile).  Block = 8 slot-groups x 32 columns; the
+// 8 partial sums of a column are combined through LDS in a fixed order (bitwise reproducible).
 __global__ __launch_bounds__(256) void k_reduce_tiles(const float* part, int64_t ld, int ncols, float* out, int gw,
                                                       int64_t gs, int accumulate, int sub, RowsP r) {
-    __shared__ float s_acc[16][17];
-    const int cl = threadIdx.x & 15, tg = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
+    __shared__ float s_acc[8][33];
+    const int cl = threadIdx.x & 31, tg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     float s = 0.f;
     if (c < ncols) {
-        const int n_slots = r.n_tiles * sub;
-        for (int t = tg; t < n_slots; t += 16)
-            if (r.tile_seg[t / sub] >= 0) s += part[(int64_t)t * ld + c];
+        const int n_slots = r.hdr[PLAN_NTILES] * sub;          // live tiles are contiguous: no per-slot test
+#pragma unroll 8
+        for (int t = tg; t < n_slots; t += 8) s += part[(int64_t)t * ld + c];
     }
     s_acc[tg][cl] = s;
     __syncthreads();
     if (tg == 0 && c < ncols) {
         float tot = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) tot += s_acc[k][cl];
+        for (int k = 0; k < 8; ++k) tot += s_acc[k][cl];
         float* o = out + (int64_t)(c / gw) * gs + (c % gw);
         *o = accumulate ? *o + tot : tot;
     }
@@ -64,19 +65,67 @@ __global__ __launch_bounds__(256) void k_colsum(const float* X, int64_t ldx, int
     }
 }
 
-// out[g][m][n] (+)= sum_ks slab[ks][g][m][n]
-__global__ __launch_bounds__(256) void k_splitk_reduce(const float* slab, int k_split, int G, int M, int N, float* out,
-                                                       int64_t ldo, int64_t o_gs, int accumulate) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t per = (int64_t)G * M * N;
-    if (idx >= per) return;
-    float s = 0.f;
-    for (int k = 0; k < k_split; ++k) s += slab[(int64_t)k * per + idx];
-    const int g = (int)(idx / ((int64_t)M * N));
-    const int rem = (int)(idx - (int64_t)g * M * N);
-    const int m = rem / N, n = rem - m * N;
-    float* o = out + (int64_t)g * o_gs + (int64_t)m * ldo + n;
-    *o = accumulate ? *o + s : s;
+// batched split-K reduction: for every wgrad d, out[g][m][n] = sum_ks slab[ks][g][m][n]  (grid.y = d)
+struct SplitKOne { const float* slab; float* out; int k_split, G, M, N; int64_t ldo, o_gs; };
+#define MAX_WGRADS 24
+struct SplitKAllP { int n; SplitKOne d[MAX_WGRADS]; };
+__global__ __launch_bounds__(256) void k_splitk_reduce_all(const SplitKAllP a) {
+    __shared__ float s_acc[4][64];
+    const SplitKOne& p = a.d[blockIdx.y];
+    const int64_t per = (int64_t)p.G * p.M * p.N;
+    const int el = threadIdx.x & 63, kg = threadIdx.x >> 6;
+    for (int64_t base = (int64_t)blockIdx.x * 64; base < per; base += (int64_t)gridDim.x * 64) {
+        const int64_t idx = base + el;
+        float s = 0.f;
+        if (idx < per) {
+#pragma unroll 4
+            for (int k = kg; k < p.k_split; k += 4) s += p.slab[(int64_t)k * per + idx];
+        }
+        s_acc[kg][el] = s;
+        __syncthreads();
+        if (kg == 0 && idx < per) {
+            const float tot = (s_acc[0][el] + s_acc[1][el]) + (s_acc[2][el] + s_acc[3][el]);
+            const int g = (int)(idx / ((int64_t)p.M * p.N));
+            const int rem = (int)(idx - (int64_t)g * p.M * p.N);
+            const int m = rem / p.N, n = rem - m * p.N;
+            p.out[(int64_t)g * p.o_gs + (int64_t)m * p.ldo + n] = tot;
+        }
+        __syncthreads();
+    }
+}
+
+// batched per-layer column reductions at the end of the backward (grid.y = layer):
+//   db[c]     = sum over live tiles of cpart[tile][c]
+//   dbeta[c]  = sum over tiles of BatchNorm-applied, active segments of bpart[tile][c][0]
+//   dgamma[c] = ... of bpart[tile][c][1]
+struct BiasOne { const float* cpart; const float* bpart; float* db; float* dgamma; float* dbeta; int ncols, h, level; };
+struct BiasAllP { int n; BiasOne d[MAX_BN_LAYERS_DECL]; RowsP r; ModeP mp; };
+__global__ __launch_bounds__(256) void k_bias_reduce_all(const BiasAllP a) {
+    __shared__ float s_acc[3][16][17];
+    const BiasOne& p = a.d[blockIdx.y];
+    const int cl = threadIdx.x & 15, tg = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    if (blockIdx.x * 16 >= p.ncols) return;
+    float sb = 0.f, s1 = 0.f, s2 = 0.f;
+    if (c < p.ncols)
+        for (int t = tg; t < a.r.n_tiles; t += 16) {
+            const int sg = a.r.tile_seg[t];
+            if (sg < 0) continue;
+            sb += p.cpart[(int64_t)t * p.ncols + c];
+            if (a.r.seg_count[sg] <= 1) continue;
+            if (p.level >= 0 && !active_level(a.mp, p.level)[sg * MAX_TOWER + c / p.h]) continue;
+            const float* bp = p.bpart + ((int64_t)t * p.ncols + c) * 2;
+            s1 += bp[0]; s2 += bp[1];
+        }
+    s_acc[0][tg][cl] = sb; s_acc[1][tg][cl] = s1; s_acc[2][tg][cl] = s2;
+    __syncthreads();
+    if (tg < 3 && c < p.ncols) {
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tot += s_acc[tg][k][cl];
+        float* o = tg == 0 ? p.db : (tg == 1 ? p.dbeta : p.dgamma);
+        o[c] = tot;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -187,15 +236,16 @@ __global__ __launch_bounds__(256) void k_act_bwd(const ActBwdP p) {
 
 // dyhat -> dH (in place): dH = gamma*rstd*(dyhat - s1/n - xhat*s2/n); per-tile column sums of dH (bias grads)
 struct BnBwdApplyP {
-    float* d; const float* H; const float* mean; const float* rstd; const float* gamma; const float* s12;
+    float* d; const float* H; const float* mean; const float* rstd; const float* gamma; const float* bpart;
     float* cpart;                       // [n_tiles][ncols]
-    float* dgamma; float* dbeta;        // written by the blocks of tile 0: sum over BN-applied segments of s2 / s1
     int ncols, h, level;
     RowsP r; ModeP mp;
 };
 
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const BnBwdApplyP p) {
     __shared__ float s1[16][64];
+    __shared__ float s_half[2][128];
+    __shared__ float s_sum[128];                 // [col][2]: (sum dyhat, sum dyhat*xhat) of this block's segment
     const int tile = blockIdx.x, c0 = blockIdx.y * 64;
     const int seg = p.r.tile_seg[tile];
     if (seg < 0) return;
@@ -203,18 +253,19 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const BnBwdApplyP p) {
     const int rg = threadIdx.x >> 4, cq = threadIdx.x & 15;
     const int c = c0 + cq * 4;
     const bool col_ok = c < p.ncols;
-    if (tile == 0 && threadIdx.x < 64 && c0 + threadIdx.x < p.ncols) {       // BatchNorm affine gradients
-        const int cc = c0 + threadIdx.x;
-        float dg = 0.f, db = 0.f;
-        for (int sg = 0; sg < p.r.n_seg; ++sg) {
-            if (p.r.seg_count[sg] <= 1) continue;
-            if (p.level >= 0 && !active_level(p.mp, p.level)[sg * MAX_TOWER + cc / p.h]) continue;
-            db += p.s12[((int64_t)sg * p.ncols + cc) * 2];
-            dg += p.s12[((int64_t)sg * p.ncols + cc) * 2 + 1];
-        }
-        p.dgamma[cc] = dg; p.dbeta[cc] = db;
-    }
+    const int ncol_here = (p.ncols - c0 < 64 ? p.ncols - c0 : 64) * 2;
     const int cnt = p.r.seg_count[seg];
+    {   // per-segment sums for this block's 64 columns, fixed order: two interleaved halves, then combined
+        const int t0 = p.r.seg_start[seg] / TILE_M, nt = (cnt + TILE_M - 1) / TILE_M;
+        const int v = threadIdx.x & 127, half = threadIdx.x >> 7;
+        float acc = 0.f;
+        if (v < ncol_here)
+            for (int t = half; t < nt; t += 2) acc += p.bpart[((int64_t)(t0 + t) * p.ncols + c0) * 2 + v];
+        s_half[half][v] = acc;
+        __syncthreads();
+        if (threadIdx.x < 128) s_sum[threadIdx.x] = s_half[0][threadIdx.x] + s_half[1][threadIdx.x];
+        __syncthreads();
+    }
     bool act = col_ok;
     if (act && p.level >= 0) act = active_level(p.mp, p.level)[seg * MAX_TOWER + c / p.h] != 0;
     const bool bn = cnt > 1 && act;     // inactive towers: d is already zero and H was never written
@@ -226,7 +277,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const BnBwdApplyP p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             mu[i] = p.mean[so + i]; rs[i] = p.rstd[so + i]; ga[i] = p.gamma[c + i];
-            m1[i] = p.s12[(so + i) * 2] * inv_n; m2[i] = p.s12[(so + i) * 2 + 1] * inv_n;
+            m1[i] = s_sum[(cq * 4 + i) * 2] * inv_n; m2[i] = s_sum[(cq * 4 + i) * 2 + 1] * inv_n;
         }
     }
     for (int rr = rg; rr < nvalid; rr += 16) {

@@ -20,6 +20,7 @@ struct RowsP {                       // the parts of the row plan a kernel needs
     const int32_t* row_sample;
     const int32_t* seg_count;
     const int32_t* seg_start;
+    const int32_t* hdr;              // plan header: hdr[PLAN_NTILES] = number of live tiles (they are contiguous from 0)
     int n_tiles, n_seg;
 };
 

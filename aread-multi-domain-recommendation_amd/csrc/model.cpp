@@ -169,7 +169,6 @@ extern "C" int aread_model_l2_coef(const aread_model* m, float* coef) {
 // ------------------------------------------------------------------------------------------------
 // workspace
 // ------------------------------------------------------------------------------------------------
-#define WGRAD_KCHUNK 1024
 
 static int64_t take(int64_t* o, int64_t n) {
     int64_t r = *o;
@@ -226,17 +225,20 @@ void ws_layout(const aread_model* m, int64_t B, int n_seg, WsLayout* w) {
     w->seg_dom = take(&o, MAX_SEG);
     w->loss_part = take(&o, tiles * 4);
     w->gate_part = take(&o, tiles * 4 * m->ld_gt);
-    // split-K slabs of the largest wgrad
-    const int ksplit = (int)((rows + WGRAD_KCHUNK - 1) / WGRAD_KCHUNK);
-    int64_t slab = 0;
-    auto upd = [&](int64_t g, int64_t mm, int64_t nn) { int64_t s = g * mm * nn; if (s > slab) slab = s; };
-    for (int j = 0; j < m->experts.n_layers; ++j) upd(m->experts.L[j].G, m->experts.L[j].out_dim, m->experts.L[j].in_dim);
+    // split-K slabs, one region per wgrad so that all of them can be reduced by one launch at the end
+    auto slab = [&](int G, int M, int N) { return take(&o, (int64_t)G * M * N * wgrad_ksplit(rows, G, M, N).k_split); };
+    for (int j = 0; j < m->experts.n_layers; ++j) {
+        const LayerL& L = m->experts.L[j];
+        w->slab_ex[j] = (L.in_gs == 0 && L.G > 1) ? slab(1, L.ncols, L.in_dim) : slab(L.G, L.out_dim, L.in_dim);
+    }
     for (int l = 0; l < c.n_level; ++l)
-        for (int j = 0; j < m->towers[l].n_layers; ++j) upd(m->towers[l].L[j].G, m->towers[l].L[j].out_dim, m->towers[l].L[j].in_dim);
-    upd(1, m->n_heads, D);
-    upd(1, c.n_tower[0] * c.n_expert, D);
-    upd(1, m->gate_rows, 2 * E);
-    w->slab = take(&o, slab * ksplit);
+        for (int j = 0; j < m->towers[l].n_layers; ++j) {
+            const LayerL& L = m->towers[l].L[j];
+            w->slab_tw[l][j] = slab(L.G, L.out_dim, L.in_dim);
+        }
+    w->slab_head = slab(1, m->n_heads, D);
+    w->slab_gate = slab(1, c.n_tower[0] * c.n_expert, D);
+    w->slab_tgate = slab(1, m->gate_rows > 0 ? m->gate_rows : 1, 2 * E);
     w->rw_part = take(&o, tiles * 4 * ((int64_t)(2 * MAX_CROSS + 1) * D + 4));
     w->misc_part = take(&o, tiles * 4 * 1024);
     w->total = o;

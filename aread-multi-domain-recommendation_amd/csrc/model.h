@@ -56,8 +56,25 @@ struct WsLayout {                            // float offsets into the workspace
     LayerWs tw[AREAD_MAX_LEVEL][AREAD_MAX_LAYER];
     int64_t active;                          // bytes region (as float offset): [n_level][MAX_SEG][MAX_TOWER]
     int64_t kact, seg_dom;                   // ints: active heads per seg, domain of each seg
-    int64_t loss_part, gate_part, slab, rw_part, misc_part;
+    int64_t loss_part, gate_part, rw_part, misc_part;
+    int64_t slab_ex[AREAD_MAX_LAYER], slab_tw[AREAD_MAX_LEVEL][AREAD_MAX_LAYER], slab_head, slab_gate, slab_tgate;
     int64_t total;                           // floats
 };
 
 void ws_layout(const aread_model* m, int64_t B, int n_seg, WsLayout* w);
+
+// split-K geometry of a wgrad GEMM (K = padded batch rows): enough slices to fill the chip
+struct KSplit { int k_split, k_chunk; };
+static inline KSplit wgrad_ksplit(int64_t rows, int G, int M, int N) {
+    const int tn = N > 64 ? 128 : (N > 32 ? 64 : (N > 16 ? 32 : 16));
+    const int64_t blocks_mn = (int64_t)G * ((M + 63) / 64) * ((N + tn - 1) / tn);
+    int64_t want = (768 + blocks_mn - 1) / blocks_mn;
+    const int64_t max_split = rows / TILE_M;
+    if (want > max_split) want = max_split;
+    if (want < 1) want = 1;
+    int64_t chunk = ((rows + want - 1) / want + TILE_M - 1) / TILE_M * TILE_M;
+    KSplit k;
+    k.k_chunk = (int)chunk;
+    k.k_split = (int)((rows + chunk - 1) / chunk);
+    return k;
+}
