@@ -6,5 +6,6 @@ from . import _lib                                  # noqa: F401
 from .layer import FeaturesEmbedding                # noqa: F401
 from .plan import RowPlan                           # noqa: F401
 from .aread import AREAD, pack_masks                # noqa: F401
+from . import dist                                  # noqa: F401
 
 __all__ = ["FeaturesEmbedding", "RowPlan", "AREAD", "pack_masks"]

@@ -460,11 +460,11 @@ class AREAD(nn.Module):
         )
         return bufs
 
-    def train_step(self, x, y, bufs, masks_dev=None, domain_i=None, seg_weight=None, with_reg=True, set_grads=True,
-                   want_gates=False):
-        """forward + bagging BCE + L2 + backward to every parameter gradient, no host sync, no allocation
-        besides the row plan (run.py:668-680 without the optimizer).  y: float32 [B] on the device.
-        Returns the device scalar loss = sum_d w_d*bag_d + reg."""
+    def step_local(self, x, y, bufs, masks_dev=None, domain_i=None, seg_weight=None, with_reg=True,
+                   with_dense_l2=True, want_gates=False):
+        """Rank-local part of the step: row plan, gather, dense forward + bagging BCE + backward, table L2 pass
+        (bufs['gtable'] = 2*l2*W, bufs['reg'] = l2 terms).  Leaves bufs['de'] (gradient w.r.t. the pooled
+        embedding, plan order) for step_scatter.  No host sync, no allocation besides the row plan."""
         lib = L.lib()
         n_seg = bufs["n_seg"]
         table = self.embedding.embedding_dict.weight
@@ -479,15 +479,32 @@ class AREAD(nn.Module):
             L.check(lib.aread_l2_table(L.ptr(table), table.numel(), self.l2_reg_embedding, 1.0, L.ptr(bufs["gtable"]),
                                        L.ptr(part), L.stream()))
             L.check(lib.aread_l2_finish(L.ptr(part), part.numel(), self.l2_reg_embedding, L.ptr(bufs["reg"]), 0, L.stream()))
-            L.check(lib.aread_l2_dense(L.ptr(self.dense), L.ptr(self._l2_coef(x.device)), self.dense.numel(),
-                                       L.ptr(bufs["gdense"]), L.ptr(bufs["reg"]), 1, L.stream()))
+            if with_dense_l2:
+                self.add_dense_l2(bufs)
         else:
             bufs["gtable"].zero_()
             bufs["reg"].zero_()
-        self.embedding.scatter_grad(x, bufs["de"], bufs["gtable"], st.plan.sample_row)
+        self._last = (st, gate)
+        return st
+
+    def add_dense_l2(self, bufs):
+        """reg += sum coef*w^2 over the dense tensors, gdense += 2*coef*w (once per step, after any all-reduce)."""
+        L.check(L.lib().aread_l2_dense(L.ptr(self.dense), L.ptr(self._l2_coef(self.dense.device)), self.dense.numel(),
+                                       L.ptr(bufs["gdense"]), L.ptr(bufs["reg"]), 1, L.stream()))
+
+    def step_scatter(self, x, de, sample_row, gtable):
+        """gtable[g] += contributions of (x, de): the embedding backward (sorted segmented reduction)."""
+        self.embedding.scatter_grad(x, de, gtable, sample_row)
+
+    def train_step(self, x, y, bufs, masks_dev=None, domain_i=None, seg_weight=None, with_reg=True, set_grads=True,
+                   want_gates=False):
+        """forward + bagging BCE + L2 + backward to every parameter gradient, no host sync, no allocation
+        besides the row plan (run.py:668-680 without the optimizer).  y: float32 [B] on the device.
+        Returns the device scalar loss = sum_d w_d*bag_d + reg."""
+        st = self.step_local(x, y, bufs, masks_dev, domain_i, seg_weight, with_reg, True, want_gates)
+        self.step_scatter(x, bufs["de"], st.plan.sample_row, bufs["gtable"])
         torch.add(bufs["loss"][:1], bufs["reg"][:1], out=bufs["total"])
         if set_grads:
             self.dense.grad = bufs["gdense"]
-            table.grad = bufs["gtable"]
-        self._last = (st, gate)
+            self.embedding.embedding_dict.weight.grad = bufs["gtable"]
         return bufs["total"]

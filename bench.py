@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=6)
     ap.add_argument("--dropout", type=float, default=0.2)
     ap.add_argument("--domain-dist", default="proportional", choices=["proportional", "uniform"])
+    ap.add_argument("--force-dp", action="store_true", help="use the multi-GPU code path even with one rank (testing)")
     return ap.parse_args()
 
 
@@ -58,11 +59,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    use_dp = world > 1 or args.force_dp
+    if use_dp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from oracle import aread_oracle as O          # spec + deterministic initialiser (+ cpu_baseline leg below)
     from tools import synth
@@ -84,17 +87,32 @@ def main():
     for _ in range(n_batches):
         x, y = synth.amazon_batch(spec, rng, B, domain=args.domain_dist)
         batches.append((torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev), x, y))
-    bufs = model.make_step_buffers(B, multi_domain=True, device=dev)
     xs = torch.empty_like(batches[0][0])
     ys = torch.empty_like(batches[0][1])
+    dp_state = {}
+    if use_dp:
+        from aread_amd.dist import DataParallelStep
+        dp = DataParallelStep(model, B)
+        bufs = dp.bufs
 
-    def step():
-        return model.train_step(xs, ys, bufs, masks_dev=masks_dev, set_grads=False)
+        def step():                                   # rank-local part (graph-captured)
+            dp_state["st"] = dp.local(xs, ys, masks_dev)
+
+        def after():                                  # collectives + global scatter (eager)
+            dp.exchange_and_scatter(xs, dp_state["st"])
+    else:
+        bufs = model.make_step_buffers(B, multi_domain=True, device=dev)
+
+        def step():
+            return model.train_step(xs, ys, bufs, masks_dev=masks_dev, set_grads=False)
+
+        def after():
+            pass
 
     # ---- warm-up (also sizes the embedding-backward workspace) ---------------------------------------
     xs.copy_(batches[0][0]); ys.copy_(batches[0][1])
     log("first eager step")
-    step()
+    step(); after()
     torch.cuda.synchronize()
     log("first step done")
     graph = None
@@ -124,22 +142,23 @@ def main():
             graph.replay()
         else:
             step()
+        after()
 
     for i in range(args.warmup):
         run_one(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dp:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         run_one(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dp:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dp:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
@@ -161,14 +180,15 @@ def main():
                    "batch_per_gpu": B, "global_batch": B * world, "domain_dist": args.domain_dist,
                    "dropout": args.dropout, "mask_active_frac": 0.7, "optimizer_in_timed_region": False,
                    "dense_table_l2_in_timed_region": True, "launch": "hipGraph replay" if graph is not None else "eager",
-                   "parallelism": f"dp{world}"},
+                   "parallelism": f"dp{world}" + (": replicated table, all_gather(ids,dE)+all_reduce(dense grads) over RCCL"
+                                                   if use_dp else "")},
         "roofline": roofline, "gather_roofline": gather, "loss": round(loss, 6),
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(O, spec, P, masks, batches, args)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dp:
         dist.destroy_process_group()
 
 

@@ -1,0 +1,94 @@
+"""CPU, gloo, world_size 2: the multi-GPU exchange logic (aread_amd/dist.py).
+
+The collectives and row-map rebasing run for real; the local compute is stood in by the oracle's
+scatter (tests may use the oracle, the product path may not)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import aread_oracle as O
+from tests import util as U
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_data(spec, rank, B, rows):
+    rng = np.random.default_rng(100 + rank)
+    x = np.stack([rng.integers(0, d, B) for d in spec.field_dims]
+                 + [rng.integers(0, spec.field_dims[0] + 1, B) for _ in range(spec.n_mh_slots)], axis=1).astype(np.int32)
+    perm = rng.permutation(rows)[:B].astype(np.int32)            # a row plan: sample b lives in row perm[b]
+    de = rng.standard_normal((rows, spec.d)).astype(np.float32)
+    g = rng.standard_normal(50).astype(np.float32)
+    return x, perm, de, g
+
+
+def _scatter_ref(spec, x, sample_row, de):
+    """oracle scatter: table_grad[bag[b,j]] += c_j * de[sample_row[b], out_field(j)]"""
+    bag = O.index_bag(x, spec).astype(np.int64)
+    out = np.zeros((spec.rows, spec.embed_dim), np.float64)
+    de3 = de.reshape(de.shape[0], spec.f_out, spec.embed_dim).astype(np.float64)
+    for j in range(spec.f_in):
+        mh = j >= spec.n_onehot
+        fo = spec.n_onehot + (j - spec.n_onehot) // spec.seq_maxlen if mh else j
+        c = 1.0 / spec.seq_maxlen if (mh and spec.method == "mean") else 1.0
+        np.add.at(out, bag[:, j], c * de3[sample_row, fo, :])
+    return out
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import aread_amd.dist as D
+        spec = U.spec_full()
+        B, rows = 40, 64
+        x, perm, de, g = _rank_data(spec, rank, B, rows)
+        x_all, sr_all, de_all = D.gather_sparse_grad_inputs(torch.from_numpy(x), torch.from_numpy(perm),
+                                                            torch.from_numpy(de))
+        gsum = D.reduce_dense_grad(torch.from_numpy(g.copy()))
+        got = _scatter_ref(spec, x_all.numpy(), sr_all.numpy().astype(np.int64), de_all.numpy())
+        # expected: the sum of every rank's own scatter (rank-local data regenerated from the seeds)
+        exp = np.zeros_like(got)
+        gexp = np.zeros_like(g)
+        for r in range(world):
+            xr, pr, dr, gr = _rank_data(spec, r, B, rows)
+            exp += _scatter_ref(spec, xr, pr.astype(np.int64), dr)
+            gexp += gr
+        ok = (np.allclose(got, exp, rtol=1e-12, atol=1e-12) and np.allclose(gsum.numpy(), gexp, rtol=1e-6)
+              and x_all.shape == (world * B, spec.f_in) and de_all.shape == (world * rows, spec.d))
+        # replicas must agree bit for bit: gather every rank's result on rank 0
+        t = torch.from_numpy(got.astype(np.float32))
+        outs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(outs, t)
+        same = all(torch.equal(outs[0], o) for o in outs)
+        q.put((rank, bool(ok), bool(same)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_gather_and_reduce_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=100) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=30)
+    assert sorted(r[0] for r in res) == list(range(world))
+    assert all(r[1] for r in res), res
+    assert all(r[2] for r in res), res

@@ -199,3 +199,35 @@ def test_dropout_matches_oracle_hash():
             assert not ref.any(), k
             continue
         np.testing.assert_allclose(got[k], ref, rtol=1e-3, atol=5e-5 * max(np.abs(ref).max(), 1e-4), err_msg=k)
+
+
+def test_dp_path_single_rank_matches_fused_step():
+    """aread_amd.dist.DataParallelStep on RCCL with one rank == the fused single-GPU step, bit for bit."""
+    import torch.distributed as dist
+    import aread_amd
+    from aread_amd.dist import DataParallelStep
+    fn, mk, seed = U.GOLDEN_MODELS["full"]
+    G, spec = U.load_golden(fn), mk()
+    masks = U.golden_masks(spec, G, "rand")
+    x = torch.from_numpy(G["multi_rand/x"]).cuda()
+    y = torch.from_numpy(G["multi_rand/y"].astype(np.float32)).cuda()
+    res = []
+    os_env = __import__("os").environ
+    os_env.setdefault("MASTER_ADDR", "127.0.0.1"); os_env.setdefault("MASTER_PORT", "29577")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        for use_dp in (False, True):
+            model, _ = U.build_model(spec, seed)
+            model.train()
+            md = aread_amd.pack_masks(masks, spec.n_domain, model.edge_num, "cuda")
+            if use_dp:
+                dp = DataParallelStep(model, x.shape[0])
+                loss = dp.step(x, y, md); bufs = dp.bufs
+            else:
+                bufs = model.make_step_buffers(x.shape[0])
+                loss = model.train_step(x, y, bufs, masks_dev=md, set_grads=False)
+            res.append((float(loss), bufs["gdense"].clone(), bufs["gtable"].clone()))
+    finally:
+        dist.destroy_process_group()
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
