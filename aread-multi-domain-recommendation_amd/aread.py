@@ -18,6 +18,7 @@ import torch
 from torch import nn
 
 from . import _lib as L
+from .hemp import HempMixin
 from .layer import FeaturesEmbedding
 from .plan import RowPlan
 
@@ -131,7 +132,7 @@ class _RegFn(torch.autograd.Function):
         return gtab, gd, None
 
 
-class AREAD(nn.Module):
+class AREAD(HempMixin, nn.Module):
     """Adaptive REcommendation for All Domains -- model/aread.py:15-322 on MI355X."""
 
     def __init__(self, one_hot_feature_dims, embed_dim, multi_hot_dict, n_tower, n_domain, base_model,

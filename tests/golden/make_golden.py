@@ -295,6 +295,16 @@ def spec_tiny():
                   atten_embed_dim=64)
 
 
+def gen_hemp(path):
+    """Mask sequences of the reference's HEMP host logic under fixed seeds (tests/util.py::hemp_sequence)."""
+    from tests.util import hemp_sequence
+    spec = spec_full()
+    model, _ = build_reference(spec, 123)
+    out = hemp_sequence(model, spec)
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {len(out)} arrays")
+
+
 if __name__ == "__main__":
     torch.manual_seed(2000)
     np.random.seed(2000)
@@ -302,3 +312,4 @@ if __name__ == "__main__":
     gen_embedding(os.path.join(HERE, "embedding.npz"))
     gen_model(os.path.join(HERE, "aread_full.npz"), spec_full(), 123, "full widths")
     gen_model(os.path.join(HERE, "aread_tiny.npz"), spec_tiny(), 321, "tiny/odd widths")
+    gen_hemp(os.path.join(HERE, "hemp.npz"))

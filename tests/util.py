@@ -101,3 +101,70 @@ def dense_grads(model, flat=None):
             n = int(np.prod(shape)) if shape else 1
             out[name] = g[off:off + n].reshape(shape)
     return out
+
+
+# ---- HEMP host-logic sequence: driven identically on the reference (golden generation) and on aread_amd ----
+def hemp_sequence(model, spec, seed=7):
+    """Run a fixed sequence of mask operations under fixed numpy/torch seeds; returns {name: uint8 array}.
+    Inputs that are not part of the model's own random stream come from a private Generator."""
+    import contextlib, io
+    import torch
+    out = {}
+    rng = np.random.default_rng(seed + 100)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    pk = lambda m: O.pack_mask(spec, m)
+    n = spec.n_tower
+    with contextlib.redirect_stdout(io.StringIO()):
+        model.reset_for_mask_update()
+        for i, p in enumerate([0.7, 0.7, 0.5, 0.3, 0.3, 0.15]):
+            out[f"rand/{i}"] = pk(model.generate_mask("rand", init_active_percent=p))
+        for i in range(24):                                           # validity closure on raw random masks
+            p = [0.15, 0.3, 0.5, 0.8][i % 4]
+            raw = [rng.random(s.shape) < p for s in O.full_mask(spec)]
+            m = [r.copy() for r in raw] if i % 2 == 0 else [torch.tensor(r) for r in raw]
+            out[f"validate/{i}/in"] = pk(raw)
+            out[f"validate/{i}/out"] = pk(model.validate_mask(m))
+        # gate statistics recorded by warm-up steps -> 'mask_max_gate' candidates (run.py:628-630)
+        for d in range(3):
+            for l in range(1, spec.n_level):
+                for t in range(n[l]):
+                    for _ in range(3):
+                        g = rng.random(n[l - 1]).astype(np.float32)
+                        g = g / g.sum() * (rng.random() < 0.85)
+                        model.domain_tower_gate_values[d][l][t].append(torch.from_numpy(g.astype(np.float32)))
+        for d in range(3):
+            m1 = model.generate_mask("mask_max_gate", d=d, init_active_percent=0.7, random_modify_sigma=0.2)
+            out[f"mmg/{d}/first"] = pk(m1)
+            model.domain_mask[d] = m1
+            out[f"mmg/{d}/second"] = pk(model.generate_mask("mask_max_gate", d=d, init_active_percent=0.4,
+                                                             random_modify_sigma=0.3))
+            out[f"mnr/{d}"] = pk(model.generate_mask("mask_norm_rand", d=d, random_modify_sigma=0.25))
+            out[f"mgnr/{d}"] = pk(model.generate_mask("max_gate_norm_rand", d=d, init_active_percent=0.6,
+                                                       random_modify_sigma=0.2))
+        # a domain with no recorded statistics falls back to 'rand' inside mask_max_gate
+        out["mmg/empty"] = pk(model.generate_mask("mask_max_gate", d=4 % spec.n_domain, init_active_percent=0.7,
+                                                  random_modify_sigma=0.2))
+        # pruning with the gate means of one fast-update step
+        for i in range(6):
+            cur = model.generate_mask("rand", init_active_percent=0.8)
+            for l in range(1, spec.n_level):
+                for t in range(n[l]):
+                    col = cur[l][:, t].numpy().astype(np.float32)
+                    g = rng.random(n[l - 1]).astype(np.float32) * col
+                    model.tmp_tower_gate_values[l][t] = torch.from_numpy(g / max(g.sum(), 1e-6) * (g.sum() > 0))
+            out[f"prune/{i}/in"] = pk(cur)
+            res = model.prun_single_mask(0, cur, prun_ratio=[0.05, 0.3, 0.6][i % 3])
+            out[f"prune/{i}/out"] = pk(res)
+        # selection
+        model.reset_for_mask_update()
+        for d in range(spec.n_domain):
+            for z in range(3):
+                model.candidate_domain_mask[d].append(model.generate_mask("rand", init_active_percent=0.6))
+                for _ in range(4):
+                    model.add_eval_loss(float(rng.random()), d=d, mask_z=z)
+        model.update_all_mask(regroup_times=1)
+        for d in range(spec.n_domain):
+            out[f"select/{d}"] = pk(model.domain_mask[d])
+        out["active_ratio"] = np.array([model.count_current_active_ratio()])
+    return out
