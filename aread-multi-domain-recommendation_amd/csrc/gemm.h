@@ -41,11 +41,22 @@ struct GemmP {
     float* stat_part; int64_t stat_ld;       // stat_part[(tile_m*stat_ld + g*N + n)*2 + {0,1}]
 };
 
+// LDS image of an operand tile.  KC operands: [rows][BK+2] (k contiguous, as in global memory).
+// MC operands: [BK][PITCH_R] (rows contiguous, as in global memory) -- no transposition on the way in, the
+// staging stores are whole 16-byte vectors.  Both pitches put the 4 k-slices of a fragment read on
+// disjoint bank groups (PITCH_R = 16 mod 32).
 template <int ROWS, bool KC>
 struct TileLoader {
     // number of float4 each thread moves per k-tile
     static constexpr int F4 = (ROWS * GEMM_BK / 4 + GEMM_THREADS - 1) / GEMM_THREADS;
+    static constexpr int PITCH_R = (ROWS % 32 == 0) ? ROWS + 16 : ROWS;
+    static constexpr int LDS_FLOATS = KC ? ROWS * GEMM_PITCH : GEMM_BK * PITCH_R;
     float4 v[F4];
+
+    // fragment element (row r, k) of the staged tile
+    static __device__ __forceinline__ int frag_offset(int r, int k) { return KC ? r * GEMM_PITCH + k : k * PITCH_R + r; }
+    static constexpr int ROW_STEP = KC ? GEMM_PITCH : 1;     // +1 row
+    static constexpr int K_STEP = KC ? 1 : PITCH_R;          // +1 k
 
     __device__ __forceinline__ void load(const float* __restrict__ base, int64_t ld, int r0, int r_end, int k0,
                                          int k_end) {
@@ -103,13 +114,7 @@ struct TileLoader {
             } else {
                 constexpr int Q = ROWS / 4;
                 const int krow = idx / Q, mq = idx - krow * Q;
-                if (krow < GEMM_BK) {
-                    float* d = lds + (4 * mq) * GEMM_PITCH + krow;
-                    d[0] = v[p].x;
-                    d[GEMM_PITCH] = v[p].y;
-                    d[2 * GEMM_PITCH] = v[p].z;
-                    d[3 * GEMM_PITCH] = v[p].w;
-                }
+                if (krow < GEMM_BK) *(float4*)(lds + krow * PITCH_R + 4 * mq) = v[p];
             }
         }
     }
@@ -118,8 +123,10 @@ struct TileLoader {
 template <int NI, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(GEMM_THREADS) void k_gemm(const GemmP p) {
     constexpr int TM = 64, TN = 16 * NI;
-    __shared__ __attribute__((aligned(16))) float As[TM * GEMM_PITCH];
-    __shared__ __attribute__((aligned(16))) float Bs[TN * GEMM_PITCH];
+    using LA = TileLoader<TM, A_KC>;
+    using LB = TileLoader<TN, B_KC>;
+    __shared__ __attribute__((aligned(16))) float As[LA::LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float Bs[LB::LDS_FLOATS];
     __shared__ float s_red[4][TN];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -153,8 +160,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm(const GemmP p) {
         return k0;
     };
 
-    TileLoader<TM, A_KC> la;
-    TileLoader<TN, B_KC> lb;
+    LA la;
+    LB lb;
     int k0 = next_live(k_begin);
     if (k0 < k_end) {
         la.load(Ag, p.lda, m0, p.M, k0, k_end);
@@ -170,14 +177,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm(const GemmP p) {
             la.load(Ag, p.lda, m0, p.M, kn, k_end);
             lb.load(Bg, p.ldb, n0, p.N, kn, k_end);
         }
-        const float* ap = As + (wave * 16 + fr) * GEMM_PITCH + fk;
-        const float* bp = Bs + fr * GEMM_PITCH + fk;
+        const float* ap = As + LA::frag_offset(wave * 16 + fr, fk);
+        const float* bp = Bs + LB::frag_offset(fr, fk);
 #pragma unroll
         for (int kk = 0; kk < GEMM_BK / 4; ++kk) {
-            const float a = ap[kk * 4];
+            const float a = ap[kk * 4 * LA::K_STEP];
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                const float b = bp[i * 16 * GEMM_PITCH + kk * 4];
+                const float b = bp[i * 16 * LB::ROW_STEP + kk * 4 * LB::K_STEP];
                 acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
             }
         }
@@ -254,4 +261,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm(const GemmP p) {
     }
 }
 
+// number of 16-column MFMA tiles per wave: 96-wide tiles when they cover N with less padding than 128-wide ones
+static inline int gemm_ni(int N) {
+    if (N > 64) {
+        const int w128 = (N + 127) / 128 * 128, w96 = (N + 95) / 96 * 96;
+        return w96 < w128 ? 6 : 8;
+    }
+    return N > 32 ? 4 : (N > 16 ? 2 : 1);
+}
 int launch_gemm(const GemmP& p, bool a_kc, bool b_kc, hipStream_t st);

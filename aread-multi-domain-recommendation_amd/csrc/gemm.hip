@@ -20,10 +20,11 @@ int launch_gemm(const GemmP& p_in, bool a_kc, bool b_kc, hipStream_t st) {
     if (p.k_split == 1) p.k_chunk = p.K;
     AR_CHECK_ARG(p.k_split == 1 || p.k_chunk % TILE_M == 0, "gemm: k_chunk must be a multiple of %d", TILE_M);
     AR_CHECK_ARG(p.gate_axis == 0 || p.tile_seg != nullptr, "gemm: gating needs tile_seg");
-    const int ni = p.N > 64 ? 8 : (p.N > 32 ? 4 : (p.N > 16 ? 2 : 1));
+    const int ni = gemm_ni(p.N);
     dim3 grid(cdiv(p.N, 16 * ni), cdiv(p.M, 64), p.G * p.k_split);
     switch (ni) {
         case 8: launch_ni<8>(p, a_kc, b_kc, grid, st); break;
+        case 6: launch_ni<6>(p, a_kc, b_kc, grid, st); break;
         case 4: launch_ni<4>(p, a_kc, b_kc, grid, st); break;
         case 2: launch_ni<2>(p, a_kc, b_kc, grid, st); break;
         default: launch_ni<1>(p, a_kc, b_kc, grid, st); break;

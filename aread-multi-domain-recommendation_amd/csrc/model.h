@@ -66,7 +66,8 @@ void ws_layout(const aread_model* m, int64_t B, int n_seg, WsLayout* w);
 // split-K geometry of a wgrad GEMM (K = padded batch rows): enough slices to fill the chip
 struct KSplit { int k_split, k_chunk; };
 static inline KSplit wgrad_ksplit(int64_t rows, int G, int M, int N) {
-    const int tn = N > 64 ? 128 : (N > 32 ? 64 : (N > 16 ? 32 : 16));
+    int tn = N > 32 ? 64 : (N > 16 ? 32 : 16);
+    if (N > 64) tn = ((N + 95) / 96 * 96 < (N + 127) / 128 * 128) ? 96 : 128;
     const int64_t blocks_mn = (int64_t)G * ((M + 63) / 64) * ((N + tn - 1) / tn);
     int64_t want = (768 + blocks_mn - 1) / blocks_mn;
     const int64_t max_split = rows / TILE_M;
