@@ -43,7 +43,7 @@ class Call(C.Structure):
                 ("update_running", C.c_int32), ("domain", C.c_int32), ("drop_seed", C.c_uint32),
                 ("plan", C.c_void_p), ("masks", C.c_void_p), ("params", C.c_void_p), ("stats", C.c_void_p),
                 ("nbt", C.c_void_p), ("ws", C.c_void_p), ("probs", C.c_void_p), ("gate_stats", C.c_void_p),
-                ("y", C.c_void_p), ("seg_weight", C.c_void_p), ("loss_out", C.c_void_p)]
+                ("y", C.c_void_p), ("seg_weight", C.c_void_p), ("loss_out", C.c_void_p), ("async_tail", C.c_int32)]
 
 
 for _n, _r, _a in [
@@ -60,6 +60,7 @@ for _n, _r, _a in [
     ("aread_model_l2_coef", C.c_int, [C.c_void_p, C.c_void_p]),
     ("aread_forward", C.c_int, [C.c_void_p, C.POINTER(Call), C.c_void_p, C.c_void_p]),
     ("aread_backward", C.c_int, [C.c_void_p, C.POINTER(Call), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("aread_join", C.c_int, [C.c_void_p, C.c_void_p]),
     ("aread_debug_ws_offset", C.c_int64, [C.c_void_p, C.c_int64, C.c_int, C.c_char_p]),
     ("aread_l2_dense", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
 ]:
@@ -220,8 +221,9 @@ class AREAD(HempMixin, nn.Module):
                 self.V_res_embedding = nn.Linear(embed_dim, a)
             self.atten_linear = nn.Linear(self.embedding.output_dim0 * a, 1, bias=False)
         self._init_dense()
-        self._coef, self._part, self._ws_cache = {}, {}, {}
+        self._coef, self._part, self._ws_cache, self._streams = {}, {}, {}, {}
         self._drop_calls = 0
+        self._pending_dense_l2 = False
         self.drop_seed_base = 0
         self.drop_seed = None          # set to an int to pin the dropout stream (tests)
         self._register_state_dict_hook(AREAD._sd_hook)
@@ -461,32 +463,57 @@ class AREAD(HempMixin, nn.Module):
         )
         return bufs
 
+    def _side_stream(self, device):
+        key = str(device)
+        if key not in self._streams:
+            self._streams[key] = torch.cuda.Stream(device=device)
+        return self._streams[key]
+
     def step_local(self, x, y, bufs, masks_dev=None, domain_i=None, seg_weight=None, with_reg=True,
-                   with_dense_l2=True, want_gates=False):
-        """Rank-local part of the step: row plan, gather, dense forward + bagging BCE + backward, table L2 pass
-        (bufs['gtable'] = 2*l2*W, bufs['reg'] = l2 terms).  Leaves bufs['de'] (gradient w.r.t. the pooled
-        embedding, plan order) for step_scatter.  No host sync, no allocation besides the row plan."""
+                   with_dense_l2=True, want_gates=False, presort=True):
+        """Rank-local part of the step: row plan, gather, dense forward + bagging BCE + backward on the current
+        stream; concurrently on a side stream (fork-join, capturable): the table L2 pass
+        (bufs['gtable'] = 2*l2*W, bufs['reg'] = l2 terms) and, with presort, the index sort of the embedding
+        backward.  Leaves bufs['de'] (gradient w.r.t. the pooled embedding, plan order) for step_scatter.
+        No host sync, no allocation besides the row plan."""
         lib = L.lib()
         n_seg = bufs["n_seg"]
         table = self.embedding.embedding_dict.weight
         if masks_dev is None:
             masks_dev = self._masks_dev(self.domain_mask, x.device)
+        plan = RowPlan(x, self.domain_idx if n_seg > 1 else -1, n_seg)
+        main, side = torch.cuda.current_stream(), self._side_stream(x.device)
+        part = self._l2_partials(x.device)
+        self.embedding._ws_for(x)                      # allocate on the main stream's pool before forking
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            if with_reg:
+                L.check(lib.aread_l2_table(L.ptr(table), table.numel(), self.l2_reg_embedding, 1.0, L.ptr(bufs["gtable"]),
+                                           L.ptr(part), L.stream()))
+                L.check(lib.aread_l2_finish(L.ptr(part), part.numel(), self.l2_reg_embedding, L.ptr(bufs["reg"]), 0,
+                                            L.stream()))
+            else:
+                bufs["gtable"].zero_()
+                bufs["reg"].zero_()
+            if presort:
+                self.embedding.sort_lookups(x, plan.sample_row)
         st, gate = self._run(x, 0, n_seg, domain_i, masks_dev, want_gates, y=y, seg_weight=seg_weight,
-                             loss_out=bufs["loss"], ws=bufs["ws"], probs=bufs["probs"], e=bufs["e"])
+                             loss_out=bufs["loss"], ws=bufs["ws"], probs=bufs["probs"], e=bufs["e"], plan=plan)
+        st.call.async_tail = 1          # parameter gradients finish on the library's side stream: see step_finish
         L.check(lib.aread_backward(self._handle, C.byref(st.call), L.ptr(st.e), None, L.ptr(bufs["gdense"]),
                                    L.ptr(bufs["de"]), L.stream()))
-        part = self._l2_partials(x.device)
-        if with_reg:
-            L.check(lib.aread_l2_table(L.ptr(table), table.numel(), self.l2_reg_embedding, 1.0, L.ptr(bufs["gtable"]),
-                                       L.ptr(part), L.stream()))
-            L.check(lib.aread_l2_finish(L.ptr(part), part.numel(), self.l2_reg_embedding, L.ptr(bufs["reg"]), 0, L.stream()))
-            if with_dense_l2:
-                self.add_dense_l2(bufs)
-        else:
-            bufs["gtable"].zero_()
-            bufs["reg"].zero_()
+        st.call.async_tail = 0
+        main.wait_stream(side)          # table L2 pass + index sort
+        self._pending_dense_l2 = bool(with_reg and with_dense_l2)
         self._last = (st, gate)
         return st
+
+    def step_finish(self, bufs):
+        """Join the library's side stream (dense parameter gradients complete) and add the dense L2 term."""
+        L.check(L.lib().aread_join(self._handle, L.stream()))
+        if self._pending_dense_l2:
+            self.add_dense_l2(bufs)
+            self._pending_dense_l2 = False
 
     def add_dense_l2(self, bufs):
         """reg += sum coef*w^2 over the dense tensors, gdense += 2*coef*w (once per step, after any all-reduce)."""
@@ -502,8 +529,9 @@ class AREAD(HempMixin, nn.Module):
         """forward + bagging BCE + L2 + backward to every parameter gradient, no host sync, no allocation
         besides the row plan (run.py:668-680 without the optimizer).  y: float32 [B] on the device.
         Returns the device scalar loss = sum_d w_d*bag_d + reg."""
-        st = self.step_local(x, y, bufs, masks_dev, domain_i, seg_weight, with_reg, True, want_gates)
-        self.step_scatter(x, bufs["de"], st.plan.sample_row, bufs["gtable"])
+        st = self.step_local(x, y, bufs, masks_dev, domain_i, seg_weight, with_reg, True, want_gates, presort=True)
+        self.embedding.reduce_sorted(x, bufs["de"], bufs["gtable"])      # overlaps the tail reductions of the backward
+        self.step_finish(bufs)
         torch.add(bufs["loss"][:1], bufs["reg"][:1], out=bufs["total"])
         if set_grads:
             self.dense.grad = bufs["gdense"]

@@ -20,8 +20,26 @@ struct Ctx {
     const float* params;
     SplitKAllP splitk;      // wgrads waiting for the batched split-K reduction
     BiasAllP bias;          // layers waiting for the batched bias-gradient reduction
+    hipStream_t side;       // fork-join side stream (wgrads, gate logits): work off the critical path
+    int ev_next;
 };
 
+// side stream waits for everything issued so far on the main stream
+static int fork_side(Ctx& x) {
+    hipEvent_t e = x.m->ev[x.ev_next++ % (x.m->n_ev - 1)];
+    AR_HIP(hipEventRecord(e, x.st));
+    AR_HIP(hipStreamWaitEvent(x.side, e, 0));
+    return AREAD_OK;
+}
+// main stream waits for everything issued so far on the side stream
+static int join_side(Ctx& x) {
+    hipEvent_t e = x.m->ev[x.ev_next++ % (x.m->n_ev - 1)];
+    AR_HIP(hipEventRecord(e, x.side));
+    AR_HIP(hipStreamWaitEvent(x.st, e, 0));
+    return AREAD_OK;
+}
+
+#define TRY0(expr) do { int _s = (expr); if (_s != AREAD_OK) return _s; } while (0)
 static int make_ctx(const aread_model* m, const aread_call* c, void* stream, Ctx* x) {
     AR_CHECK_ARG(m && c, "aread: null model/call");
     AR_CHECK_ARG(c->B > 0 && c->plan && c->params && c->ws, "aread: null plan/params/ws or B <= 0");
@@ -49,6 +67,9 @@ static int make_ctx(const aread_model* m, const aread_call* c, void* stream, Ctx
     x->params = c->params;
     x->splitk.n = 0;
     x->bias.n = 0;
+    TRY0(model_streams_init(m));
+    x->side = m->side;
+    x->ev_next = 0;
     return AREAD_OK;
 }
 
@@ -77,17 +98,14 @@ static int layer_fwd(Ctx& x, const LayerL& L, const LayerWs& lw, const float* in
     g.active = (level >= 0 && g.G > 1) ? level_active(x, level) : nullptr; g.active_ld = MAX_TOWER;
     if (x.c->train) { g.stat_part = x.ws + lw.part; g.stat_ld = L.ncols; }
     TRY(launch_gemm(g, true, true, x.st));
-    BnFinP f = {};
-    f.part = x.ws + lw.part; f.mean = x.ws + lw.mean; f.rstd = x.ws + lw.rstd; f.var = x.ws + lw.var;
-    f.rmean = x.c->stats + L.rmean; f.rvar = x.c->stats + L.rvar;
-    f.ncols = L.ncols; f.h = L.out_dim; f.train = x.c->train; f.level = level; f.r = x.r; f.mp = x.mp;
-    LAUNCH(k_bn_finalize, dim3(x.c->n_seg, cdiv(L.ncols, 16)), dim3(256), f);
     BnActP a = {};
-    a.H = x.ws + lw.H; a.Act = x.ws + lw.Act; a.mean = f.mean; a.rstd = f.rstd;
+    a.H = x.ws + lw.H; a.Act = x.ws + lw.Act; a.part = x.ws + lw.part;
+    a.mean = x.ws + lw.mean; a.rstd = x.ws + lw.rstd; a.var = x.ws + lw.var;
+    a.rmean = x.c->stats + L.rmean; a.rvar = x.c->stats + L.rvar;
     a.gamma = x.params + L.gamma; a.beta = x.params + L.beta;
     a.ncols = L.ncols; a.h = L.out_dim; a.level = level; a.stack = L.stack; a.layer = L.layer; a.train = x.c->train;
     a.seed = x.c->drop_seed; a.thr = x.thr; a.keep_scale = x.keep_scale; a.r = x.r; a.mp = x.mp;
-    LAUNCH(k_bn_act, dim3(cdiv(x.rows * (L.ncols / 4), 256)), dim3(256), a);
+    LAUNCH(k_bn_act, dim3(x.n_tiles, cdiv(L.ncols, 64)), dim3(256), a);
     return AREAD_OK;
 }
 
@@ -133,24 +151,30 @@ extern "C" int aread_forward(const aread_model* m, const aread_call* c, const fl
     mp.seg_dom = (int32_t*)(ws + x.w.seg_dom); mp.grp = ws + x.w.grp;
     LAUNCH(k_mask_prep, dim3(1), dim3(256), mp);
     if (c->probs) AR_HIP(hipMemsetAsync(c->probs, 0, (size_t)m->n_heads * c->B * sizeof(float), x.st));
-    // 2. row-wise trunk
-    RowwiseP rw = {};
-    rw.e = e_in; rw.cn = ws + x.w.cn; rw.lin = ws + x.w.lin; rw.xw = ws + x.w.xw; rw.q = ws + x.w.q; rw.grp = ws + x.w.grp;
-    rw.lin_w = P + m->lin_w; rw.lin_b = P + m->lin_b; rw.cn_w = P + m->cn_w; rw.cn_b = P + m->cn_b;
-    rw.D = D; rw.E = E; rw.n_cross = cfg.n_cross; rw.dom_field = cfg.domain_field; rw.rows = x.rows; rw.r = x.r;
-    if (D <= 256) launch_rowwise_fwd<1>(x, rw); else if (D <= 512) launch_rowwise_fwd<2>(x, rw); else launch_rowwise_fwd<4>(x, rw);
-    AR_LAUNCH_CHECK();
-    // 3. gate logits and the cross-network part of the heads
-    const int n_ge = cfg.n_tower[0] * cfg.n_expert;
-    TRY(simple_gemm(x, e_in, D, true, P + m->gate_w, D, true, ws + x.w.glogE, m->ld_ge, P + m->gate_b, (int)x.rows, n_ge, D, 0, 1));
-    if (m->gate_rows > 0)
-        TRY(simple_gemm(x, ws + x.w.q, 2 * E, true, P + m->tgate_w, 2 * E, true, ws + x.w.glogT, m->ld_gt, P + m->tgate_b,
-                        (int)x.rows, m->gate_rows, 2 * E, 0, 1));
-    TRY(simple_gemm(x, ws + x.w.cn, D, true, P + m->head_w, m->head_ld, true, ws + x.w.hc, m->ld_h, nullptr, (int)x.rows,
-                    m->n_heads, D, 0, 1));
+    // 2.+3. (side stream, joined before the MMoE mix) row-wise trunk, gate logits, cross-network part of the heads
+    TRY(fork_side(x));
+    {
+        const hipStream_t main_st = x.st;
+        x.st = x.side;
+        RowwiseP rw = {};
+        rw.e = e_in; rw.cn = ws + x.w.cn; rw.lin = ws + x.w.lin; rw.xw = ws + x.w.xw; rw.q = ws + x.w.q; rw.grp = ws + x.w.grp;
+        rw.lin_w = P + m->lin_w; rw.lin_b = P + m->lin_b; rw.cn_w = P + m->cn_w; rw.cn_b = P + m->cn_b;
+        rw.D = D; rw.E = E; rw.n_cross = cfg.n_cross; rw.dom_field = cfg.domain_field; rw.rows = x.rows; rw.r = x.r;
+        if (D <= 256) launch_rowwise_fwd<1>(x, rw); else if (D <= 512) launch_rowwise_fwd<2>(x, rw); else launch_rowwise_fwd<4>(x, rw);
+        AR_LAUNCH_CHECK();
+        const int n_ge = cfg.n_tower[0] * cfg.n_expert;
+        TRY(simple_gemm(x, e_in, D, true, P + m->gate_w, D, true, ws + x.w.glogE, m->ld_ge, P + m->gate_b, (int)x.rows, n_ge, D, 0, 1));
+        if (m->gate_rows > 0)
+            TRY(simple_gemm(x, ws + x.w.q, 2 * E, true, P + m->tgate_w, 2 * E, true, ws + x.w.glogT, m->ld_gt, P + m->tgate_b,
+                            (int)x.rows, m->gate_rows, 2 * E, 0, 1));
+        TRY(simple_gemm(x, ws + x.w.cn, D, true, P + m->head_w, m->head_ld, true, ws + x.w.hc, m->ld_h, nullptr, (int)x.rows,
+                        m->n_heads, D, 0, 1));
+        x.st = main_st;
+    }
     // 4. experts
     TRY(stack_fwd(x, m->experts, x.w.ex, e_in, -1));
     // 5. MMoE mix -> level-0 tower inputs
+    TRY(join_side(x));
     const LayerL& EL = m->experts.L[m->experts.n_layers - 1];
     Mix0P m0 = {};
     m0.glog = ws + x.w.glogE; m0.ld_g = m->ld_ge; m0.X = ws + x.w.ex[m->experts.n_layers - 1].Act; m0.In0 = ws + x.w.In[0];
@@ -214,7 +238,8 @@ static int wgrad(Ctx& x, const float* dY, int64_t ld_dy, int64_t dy_gs, const fl
     g.M = M; g.N = N; g.K = (int)x.rows; g.G = G;
     g.k_split = ks.k_split; g.k_chunk = ks.k_chunk;
     g.gate_axis = 2; g.tile_seg = x.r.tile_seg; g.tile_valid = x.r.tile_valid; g.active = active; g.active_ld = MAX_TOWER;
-    TRY(launch_gemm(g, false, false, x.st));
+    TRY(fork_side(x));                                   // everything this wgrad reads has been issued on the main stream
+    TRY(launch_gemm(g, false, false, x.side));
     AR_CHECK_ARG(x.splitk.n < MAX_WGRADS, "too many wgrads");
     SplitKOne& d = x.splitk.d[x.splitk.n++];
     d.slab = x.ws + slab_off; d.out = out; d.k_split = ks.k_split; d.G = G; d.M = M; d.N = N; d.ldo = ldo; d.o_gs = o_gs;
@@ -361,27 +386,32 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
         float* d_in = j == 0 ? de_out : ws + x.w.ex[j - 1].dAct;
         TRY(layer_bwd(x, m->experts.L[j], x.w.ex[j], in, d_in, 0, grads, -1, x.w.slab_ex[j]));
     }
-    // 6. gates
+    // 6. gate logits: dE += dglogE Gw, dq = dglogT Tw on the main stream; their weight / bias gradients on the side stream
     const int n_ge = cfg.n_tower[0] * cfg.n_expert;
+    const hipStream_t main_st = x.st;
     TRY(simple_gemm(x, ws + x.w.dglogE, m->ld_ge, true, P + m->gate_w, D, false, de_out, D, nullptr, (int)x.rows, D, n_ge, 1, 1));
+    if (m->gate_rows > 0)
+        TRY(simple_gemm(x, ws + x.w.dglogT, m->ld_gt, true, P + m->tgate_w, 2 * E, false, ws + x.w.dq, 2 * E, nullptr, (int)x.rows,
+                        2 * E, m->gate_rows, 0, 1));
+    else
+        AR_HIP(hipMemsetAsync(ws + x.w.dq, 0, (size_t)x.rows * 2 * E * sizeof(float), x.st));
     TRY(wgrad(x, ws + x.w.dglogE, m->ld_ge, 0, e_in, D, 0, 1, n_ge, D, grads + m->gate_w, D, 0, nullptr, x.w.slab_gate));
+    if (m->gate_rows > 0)
+        TRY(wgrad(x, ws + x.w.dglogT, m->ld_gt, 0, ws + x.w.q, 2 * E, 0, 1, m->gate_rows, 2 * E, grads + m->tgate_w, 2 * E, 0, nullptr,
+                  x.w.slab_tgate));
+    AR_CHECK_ARG(m->gate_rows <= 1024 && n_ge <= 1024, "aread_backward: too many gate rows");
+    x.st = x.side;                                       // (already forked by wgrad)
     LAUNCH(k_colsum, dim3(x.n_tiles), dim3(256), ws + x.w.dglogE, (int64_t)m->ld_ge, n_ge, ws + x.w.misc_part, (int64_t)1024, x.r);
     LAUNCH(k_reduce_tiles, dim3(cdiv(n_ge, 32)), dim3(256), ws + x.w.misc_part, (int64_t)1024, n_ge, grads + m->gate_b, n_ge,
            (int64_t)0, 0, 1, x.r);
     if (m->gate_rows > 0) {
-        TRY(simple_gemm(x, ws + x.w.dglogT, m->ld_gt, true, P + m->tgate_w, 2 * E, false, ws + x.w.dq, 2 * E, nullptr, (int)x.rows,
-                        2 * E, m->gate_rows, 0, 1));
-        TRY(wgrad(x, ws + x.w.dglogT, m->ld_gt, 0, ws + x.w.q, 2 * E, 0, 1, m->gate_rows, 2 * E, grads + m->tgate_w, 2 * E, 0, nullptr,
-                  x.w.slab_tgate));
-        AR_CHECK_ARG(m->gate_rows <= 1024, "aread_backward: too many gate rows");
         LAUNCH(k_colsum, dim3(x.n_tiles), dim3(256), ws + x.w.dglogT, (int64_t)m->ld_gt, m->gate_rows, ws + x.w.misc_part,
                (int64_t)1024, x.r);
         LAUNCH(k_reduce_tiles, dim3(cdiv(m->gate_rows, 32)), dim3(256), ws + x.w.misc_part, (int64_t)1024, m->gate_rows,
                grads + m->tgate_b, m->gate_rows, (int64_t)0, 0, 1, x.r);
-    } else {
-        AR_HIP(hipMemsetAsync(ws + x.w.dq, 0, (size_t)x.rows * 2 * E * sizeof(float), x.st));
     }
-    // 7. row-wise trunk backward (adds into de_out)
+    x.st = main_st;
+    // 7. row-wise trunk backward (adds into de_out): the end of the critical path
     RowwiseBwdP rb = {};
     rb.e = e_in; rb.xw = ws + x.w.xw; rb.dcn = ws + x.w.dcn; rb.dlin = ws + x.w.dlin; rb.dq = ws + x.w.dq;
     rb.lin_w = P + m->lin_w; rb.cn_w = P + m->cn_w; rb.cn_b = P + m->cn_b;
@@ -389,6 +419,9 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     rb.D = D; rb.E = E; rb.n_cross = cfg.n_cross; rb.dom_field = cfg.domain_field; rb.rows = x.rows; rb.r = x.r;
     if (D <= 256) launch_rowwise_bwd<1>(x, rb); else if (D <= 512) launch_rowwise_bwd<2>(x, rb); else launch_rowwise_bwd<4>(x, rb);
     AR_LAUNCH_CHECK();
+    // 8. everything that only finishes parameter gradients runs on the side stream
+    TRY(fork_side(x));
+    x.st = x.side;
     const float* rp = ws + x.w.rw_part;
     if (cfg.n_cross > 0) {
         LAUNCH(k_reduce_tiles, dim3(cdiv(cfg.n_cross * D, 32)), dim3(256), rp, rb.part_ld, cfg.n_cross * D, grads + m->cn_w,
@@ -400,11 +433,22 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
            (int64_t)0, 0, SUB, x.r);
     LAUNCH(k_reduce_tiles, dim3(1), dim3(256), rp + (int64_t)(2 * cfg.n_cross + 1) * D, rb.part_ld, 1, grads + m->lin_b, 1,
            (int64_t)0, 0, SUB, x.r);
-    // 8. group embedding
     LAUNCH(k_seg_reduce, dim3(c->n_seg, cdiv(E, 16)), dim3(256), ws + x.w.dgrp_part, (int64_t)E, E, ws + x.w.grp, SUB, x.r);
     LAUNCH(k_grp_bwd, dim3(1), dim3(256), ws + x.w.grp, grads + m->group_emb, cfg.n_tower[0], E, x.r, x.mp);
-    // 9. batched split-K and bias reductions of every layer
     TRY(flush_reductions(x));
+    x.st = main_st;
+    // de_out is complete on the main stream here; the parameter gradients complete on the side stream.
+    // async_tail: the caller overlaps its own work (embedding scatter) and calls aread_join() afterwards.
+    if (!c->async_tail) TRY(join_side(x));
+    return AREAD_OK;
+}
+
+extern "C" int aread_join(const aread_model* m, void* stream) {
+    AR_CHECK_ARG(m != nullptr, "aread_join: null model");
+    if (!m->side) return AREAD_OK;
+    hipEvent_t e = m->ev[m->n_ev - 1];
+    AR_HIP(hipEventRecord(e, m->side));
+    AR_HIP(hipStreamWaitEvent((hipStream_t)stream, e, 0));
     return AREAD_OK;
 }
 

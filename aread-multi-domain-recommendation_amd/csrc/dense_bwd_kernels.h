@@ -53,15 +53,27 @@ __global__ __launch_bounds__(256) void k_seg_reduce(const float* part, int64_t l
     }
 }
 
-// part[tile][c] = sum over the valid rows of the tile of X[row][c]
+// part[tile][c] = sum over the valid rows of the tile of X[row][c]     (16 row groups x 16 columns per pass)
 __global__ __launch_bounds__(256) void k_colsum(const float* X, int64_t ldx, int ncols, float* part, int64_t ldp, RowsP r) {
+    __shared__ float s_acc[16][17];
     const int tile = blockIdx.x;
     if (r.tile_seg[tile] < 0) return;
     const int nvalid = r.tile_valid[tile];
-    for (int c = threadIdx.x; c < ncols; c += 256) {
+    const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    for (int cb = 0; cb < ncols; cb += 16) {
+        const int c = cb + cl;
         float s = 0.f;
-        for (int rr = 0; rr < nvalid; ++rr) s += X[((int64_t)tile * TILE_M + rr) * ldx + c];
-        part[(int64_t)tile * ldp + c] = s;
+        if (c < ncols)
+            for (int rr = rg; rr < nvalid; rr += 16) s += X[((int64_t)tile * TILE_M + rr) * ldx + c];
+        s_acc[rg][cl] = s;
+        __syncthreads();
+        if (rg == 0 && c < ncols) {
+            float tot = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) tot += s_acc[k][cl];
+            part[(int64_t)tile * ldp + c] = tot;
+        }
+        __syncthreads();
     }
 }
 

@@ -177,111 +177,111 @@ __global__ __launch_bounds__(256) void k_rowwise_fwd(const RowwiseP p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// BatchNorm statistics: combine the per-tile (mean, M2) partials of a segment (Chan), fixed order.
-// grid (n_seg, ceil(ncols/256)).
-// ------------------------------------------------------------------------------------------------
-struct BnFinP {
-    const float* part; float* mean; float* rstd; float* var; const float* rmean; const float* rvar;
-    int ncols, h, train, level;        // level < 0: experts (always active)
-    RowsP r; ModeP mp;
-};
-
-// grid (n_seg, ceil(ncols/16)); block = 16 tile-groups x 16 columns, merged through LDS in fixed order
-__global__ __launch_bounds__(256) void k_bn_finalize(const BnFinP p) {
-    __shared__ float s_n[16][17], s_m[16][17], s_q[16][17];
-    const int seg = blockIdx.x;
-    const int cl = threadIdx.x & 15, tg = threadIdx.x >> 4;
-    const int c = blockIdx.y * 16 + cl;
-    const bool col_ok = c < p.ncols;
-    const int cnt = p.r.seg_count[seg];
-    bool act = cnt > 0 && col_ok;
-    if (act && p.level >= 0) act = active_level(p.mp, p.level)[seg * MAX_TOWER + c / p.h] != 0;
-    const bool stats = act && cnt > 1 && p.train;
-    float n = 0.f, mean = 0.f, m2 = 0.f;
-    if (stats) {
-        const int t0 = p.r.seg_start[seg] / TILE_M, nt = (cnt + TILE_M - 1) / TILE_M;
-        for (int t = tg; t < nt; t += 16) {
-            const float* pp = p.part + ((int64_t)(t0 + t) * p.ncols + c) * 2;
-            const float nb = (float)p.r.tile_valid[t0 + t], mb = pp[0], m2b = pp[1];
-            const float tot = n + nb, delta = mb - mean;
-            mean += delta * (nb / tot);
-            m2 += m2b + delta * delta * (n * nb / tot);
-            n = tot;
-        }
-    }
-    s_n[tg][cl] = n; s_m[tg][cl] = mean; s_q[tg][cl] = m2;
-    __syncthreads();
-    if (tg != 0 || !col_ok) return;
-    float rstd = 1.f, var = 0.f;
-    mean = 0.f;
-    if (act && cnt > 1) {
-        if (p.train) {
-            n = 0.f; m2 = 0.f;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const float nb = s_n[k][cl];
-                if (nb > 0.f) {
-                    const float tot = n + nb, delta = s_m[k][cl] - mean;
-                    mean += delta * (nb / tot);
-                    m2 += s_q[k][cl] + delta * delta * (n * nb / tot);
-                    n = tot;
-                }
-            }
-            var = m2 / (float)cnt;
-        } else {
-            mean = p.rmean[c];
-            var = p.rvar[c];
-        }
-        rstd = 1.0f / sqrtf(var + BN_EPS);
-    }
-    const int64_t o = (int64_t)seg * p.ncols + c;
-    p.mean[o] = mean; p.rstd[o] = rstd; p.var[o] = var;
-}
-
-// ------------------------------------------------------------------------------------------------
-// BN apply + ReLU + dropout: H -> Act   (layer.py:209-229).  One thread per float4.
+// BatchNorm statistics + apply + ReLU + dropout: H -> Act   (layer.py:209-229), one launch.
+// Block = (64-row tile, 64-column chunk).  Every block first merges the per-tile (mean, M2) partials of its
+// segment for its 64 columns (Chan, fixed order: 4 interleaved tile groups, then combined), the block of the
+// segment's first tile also publishes mean / rstd / var for the backward pass and the running statistics.
 // ------------------------------------------------------------------------------------------------
 struct BnActP {
-    const float* H; float* Act; const float* mean; const float* rstd; const float* gamma; const float* beta;
+    const float* H; float* Act; const float* part; float* mean; float* rstd; float* var;
+    const float* rmean; const float* rvar; const float* gamma; const float* beta;
     int ncols, h, level, stack, layer, train;
     uint32_t seed, thr; float keep_scale;
     RowsP r; ModeP mp;
 };
 
 __global__ __launch_bounds__(256) void k_bn_act(const BnActP p) {
-    const int c4n = p.ncols >> 2;
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t row = idx / c4n;
-    const int c = (int)(idx - row * c4n) * 4;
-    const int tile = (int)(row / TILE_M);
-    if (tile >= p.r.n_tiles) return;
+    __shared__ float s_n[4][64], s_m[4][64], s_q[4][64];
+    __shared__ float s_mean[64], s_rstd[64];
+    const int tile = blockIdx.x, c0 = blockIdx.y * 64;
     const int seg = p.r.tile_seg[tile];
     if (seg < 0) return;
-    const int rr = (int)(row - (int64_t)tile * TILE_M);
-    const int g = c / p.h;
-    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
-    bool act = rr < p.r.tile_valid[tile];
-    if (act && p.level >= 0) act = active_level(p.mp, p.level)[seg * MAX_TOWER + g] != 0;
-    if (act) {
-        const float4 hv = *(const float4*)(p.H + row * p.ncols + c);
-        float y[4] = {hv.x, hv.y, hv.z, hv.w};
-        if (p.r.seg_count[seg] > 1) {
-            const int64_t so = (int64_t)seg * p.ncols + c;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) y[i] = (y[i] - p.mean[so + i]) * p.rstd[so + i] * p.gamma[c + i] + p.beta[c + i];
+    const int nvalid = p.r.tile_valid[tile];
+    const int cnt = p.r.seg_count[seg];
+    const int t0 = p.r.seg_start[seg] / TILE_M, nt = (cnt + TILE_M - 1) / TILE_M;
+    {   // ---- statistics of this segment for columns c0 .. c0+63 -----------------------------------
+        const int cl = threadIdx.x & 63, tg = threadIdx.x >> 6;
+        const int cc = c0 + cl;
+        bool act = cc < p.ncols;
+        if (act && p.level >= 0) act = active_level(p.mp, p.level)[seg * MAX_TOWER + cc / p.h] != 0;
+        float n = 0.f, mean = 0.f, m2 = 0.f;
+        if (act && cnt > 1 && p.train) {
+            for (int t = tg; t < nt; t += 4) {
+                const float* pp = p.part + ((int64_t)(t0 + t) * p.ncols + cc) * 2;
+                const float nb = (float)p.r.tile_valid[t0 + t], mb = pp[0], m2b = pp[1];
+                const float tot = n + nb, delta = mb - mean;
+                mean += delta * (nb / tot);
+                m2 += m2b + delta * delta * (n * nb / tot);
+                n = tot;
+            }
         }
+        s_n[tg][cl] = n; s_m[tg][cl] = mean; s_q[tg][cl] = m2;
+        __syncthreads();
+        if (tg == 0) {
+            float rstd = 1.f, var = 0.f;
+            mean = 0.f;
+            if (act && cnt > 1) {
+                if (p.train) {
+                    n = 0.f; m2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) y[i] = y[i] > 0.f ? y[i] : 0.f;
-        if (p.train && p.thr) {
-            const uint32_t key = drop_row_key(p.seed, (uint32_t)p.r.row_sample[row]);
-            const uint32_t site = (uint32_t)((p.stack * 8 + p.layer) * 64 + g);
-            const int cg = c - g * p.h;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) y[i] = drop_keep(key, site, (uint32_t)(cg + i), p.thr) ? y[i] * p.keep_scale : 0.f;
+                    for (int k = 0; k < 4; ++k) {
+                        const float nb = s_n[k][cl];
+                        if (nb > 0.f) {
+                            const float tot = n + nb, delta = s_m[k][cl] - mean;
+                            mean += delta * (nb / tot);
+                            m2 += s_q[k][cl] + delta * delta * (n * nb / tot);
+                            n = tot;
+                        }
+                    }
+                    var = m2 / (float)cnt;
+                } else {
+                    mean = p.rmean[cc];
+                    var = p.rvar[cc];
+                }
+                rstd = 1.0f / sqrtf(var + BN_EPS);
+            }
+            s_mean[cl] = mean; s_rstd[cl] = rstd;
+            if (tile == t0 && cc < p.ncols) {
+                const int64_t o = (int64_t)seg * p.ncols + cc;
+                p.mean[o] = mean; p.rstd[o] = rstd; p.var[o] = var;
+            }
         }
-        out = make_float4(y[0], y[1], y[2], y[3]);
+        __syncthreads();
     }
-    *(float4*)(p.Act + row * p.ncols + c) = out;
+    // ---- apply: thread = (row group, float4) ----------------------------------------------------------
+    const int rg = threadIdx.x >> 4, cq = threadIdx.x & 15;
+    const int c = c0 + cq * 4;
+    if (c >= p.ncols) return;
+    const int g = c / p.h;
+    bool act = true;
+    if (p.level >= 0) act = active_level(p.mp, p.level)[seg * MAX_TOWER + g] != 0;
+    const bool bn = cnt > 1;
+    float mu[4], rs[4], ga[4], be[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { mu[i] = s_mean[cq * 4 + i]; rs[i] = s_rstd[cq * 4 + i]; ga[i] = p.gamma[c + i]; be[i] = p.beta[c + i]; }
+    const uint32_t site = (uint32_t)((p.stack * 8 + p.layer) * 64 + g);
+    const int cg = c - g * p.h;
+    for (int rr = rg; rr < TILE_M; rr += 16) {
+        const int64_t row = (int64_t)tile * TILE_M + rr;
+        float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (act && rr < nvalid) {
+            const float4 hv = *(const float4*)(p.H + row * p.ncols + c);
+            float y[4] = {hv.x, hv.y, hv.z, hv.w};
+            if (bn) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) y[i] = (y[i] - mu[i]) * rs[i] * ga[i] + be[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) y[i] = y[i] > 0.f ? y[i] : 0.f;
+            if (p.train && p.thr) {
+                const uint32_t key = drop_row_key(p.seed, (uint32_t)p.r.row_sample[row]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) y[i] = drop_keep(key, site, (uint32_t)(cg + i), p.thr) ? y[i] * p.keep_scale : 0.f;
+            }
+            out = make_float4(y[0], y[1], y[2], y[3]);
+        }
+        *(float4*)(p.Act + row * p.ncols + c) = out;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

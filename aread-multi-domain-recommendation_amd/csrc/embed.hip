@@ -269,17 +269,17 @@ extern "C" int64_t aread_embed_bwd_ws_bytes(int64_t B, int f_in, int E) {
     return L.total;
 }
 
-extern "C" int aread_embed_bwd(const int32_t* x, int64_t B, int f_in, const int32_t* offsets, int64_t n_table_rows,
-                               int E, int n_onehot, int n_mh_fields, int seq_len, int pool, const int32_t* sample_row,
-                               const float* dout, float* table_grad, void* ws, void* stream) {
-    AR_CHECK_ARG(x && offsets && dout && table_grad && ws, "aread_embed_bwd: null pointer");
+// phase 1 (depends only on the ids and the row map): build (table row, dout slot) pairs and sort them by row
+extern "C" int aread_embed_bwd_sort(const int32_t* x, int64_t B, int f_in, const int32_t* offsets, int64_t n_table_rows,
+                                    int E, int n_onehot, int n_mh_fields, int seq_len, int pool, const int32_t* sample_row,
+                                    void* ws, void* stream) {
+    AR_CHECK_ARG(x && offsets && ws, "aread_embed_bwd_sort: null pointer");
     AR_CHECK_ARG(E > 0 && E % 4 == 0 && E <= 256, "aread_embed_bwd: E=%d must be a multiple of 4, <= 256", E);
     AR_CHECK_ARG(pool >= 0 && pool <= 2, "aread_embed_bwd: pool=%d", pool);
     if (pool == 0) { n_onehot = f_in; n_mh_fields = 0; seq_len = 1; }
     AR_CHECK_ARG(n_onehot + n_mh_fields * seq_len == f_in, "aread_embed_bwd: field layout does not add up to f_in=%d", f_in);
     AR_CHECK_ARG(n_table_rows > 0 && n_table_rows < (1ll << 31), "aread_embed_bwd: bad table size");
-    AR_CHECK_ARG(((uintptr_t)dout & 15) == 0 && ((uintptr_t)table_grad & 15) == 0 && ((uintptr_t)ws & 255) == 0,
-                 "aread_embed_bwd: alignment");
+    AR_CHECK_ARG(((uintptr_t)ws & 255) == 0, "aread_embed_bwd: workspace alignment");
     hipStream_t st = (hipStream_t)stream;
     EmbBwdWs L;
     AR_CHECK_ARG(emb_bwd_layout(B, f_in, E, &L) == 0, "aread_embed_bwd: workspace layout failed");
@@ -288,16 +288,32 @@ extern "C" int aread_embed_bwd(const int32_t* x, int64_t B, int f_in, const int3
     uint32_t* keys_b = (uint32_t*)(base + L.off_keys_b);
     uint32_t* vals_a = (uint32_t*)(base + L.off_vals_a);
     uint32_t* vals_b = (uint32_t*)(base + L.off_vals_b);
-    int32_t* bkeys = (int32_t*)(base + L.off_bkeys);
-    float4* bvals = (float4*)(base + L.off_bvals);
     const int f_out = n_onehot + n_mh_fields;
-    const int e4 = E / 4;
     hipLaunchKernelGGL(k_embed_bwd_keys, dim3(cdiv(L.n, 256)), dim3(256), 0, st, x, offsets, sample_row, keys_a, vals_a,
                        L.n, f_in, f_out, n_onehot, seq_len, pool);
     AR_LAUNCH_CHECK();
     size_t tb = (size_t)L.temp_bytes;
     AR_HIP((rocprim::radix_sort_pairs<rocprim::default_config, uint32_t*, uint32_t*, uint32_t*, uint32_t*>(
         base + L.off_temp, tb, keys_a, keys_b, vals_a, vals_b, (size_t)L.n, 0u, (unsigned)key_bits(n_table_rows), st)));
+    return AREAD_OK;
+}
+
+// phase 2: segmented reduction of the sorted pairs into table_grad
+extern "C" int aread_embed_bwd_reduce(int64_t B, int f_in, int E, int seq_len, const float* dout, float* table_grad, void* ws,
+                                      void* stream) {
+    AR_CHECK_ARG(dout && table_grad && ws, "aread_embed_bwd_reduce: null pointer");
+    AR_CHECK_ARG(E > 0 && E % 4 == 0 && E <= 256 && seq_len >= 1, "aread_embed_bwd_reduce: bad E/seq_len");
+    AR_CHECK_ARG(((uintptr_t)dout & 15) == 0 && ((uintptr_t)table_grad & 15) == 0 && ((uintptr_t)ws & 255) == 0,
+                 "aread_embed_bwd_reduce: alignment");
+    hipStream_t st = (hipStream_t)stream;
+    EmbBwdWs L;
+    AR_CHECK_ARG(emb_bwd_layout(B, f_in, E, &L) == 0, "aread_embed_bwd: workspace layout failed");
+    char* base = (char*)ws;
+    uint32_t* keys_b = (uint32_t*)(base + L.off_keys_b);
+    uint32_t* vals_b = (uint32_t*)(base + L.off_vals_b);
+    int32_t* bkeys = (int32_t*)(base + L.off_bkeys);
+    float4* bvals = (float4*)(base + L.off_bvals);
+    const int e4 = E / 4;
     const int nw1 = SR_THREADS / e4;
     const size_t lds1 = (size_t)2 * nw1 * e4 * 16 + (size_t)2 * nw1 * 4;
     hipLaunchKernelGGL(k_embed_bwd_reduce1, dim3((unsigned)L.n_blk), dim3(SR_THREADS), lds1, st, keys_b, vals_b,
@@ -309,4 +325,14 @@ extern "C" int aread_embed_bwd(const int32_t* x, int64_t B, int f_in, const int3
                        2 * L.n_blk, e4, (float4*)table_grad);
     AR_LAUNCH_CHECK();
     return AREAD_OK;
+}
+
+extern "C" int aread_embed_bwd(const int32_t* x, int64_t B, int f_in, const int32_t* offsets, int64_t n_table_rows,
+                               int E, int n_onehot, int n_mh_fields, int seq_len, int pool, const int32_t* sample_row,
+                               const float* dout, float* table_grad, void* ws, void* stream) {
+    int st = aread_embed_bwd_sort(x, B, f_in, offsets, n_table_rows, E, n_onehot, n_mh_fields, seq_len, pool, sample_row, ws,
+                                  stream);
+    if (st != AREAD_OK) return st;
+    if (pool == 0) seq_len = 1;
+    return aread_embed_bwd_reduce(B, f_in, E, seq_len, dout, table_grad, ws, stream);
 }

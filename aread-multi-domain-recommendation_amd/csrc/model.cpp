@@ -142,7 +142,22 @@ extern "C" int aread_model_create(const aread_model_cfg* c, aread_model** out) {
     return AREAD_OK;
 }
 
-extern "C" void aread_model_destroy(aread_model* m) { delete m; }
+int model_streams_init(const aread_model* m) {
+    if (m->side) return AREAD_OK;
+    AR_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+    for (int i = 0; i < 64; ++i) AR_HIP(hipEventCreateWithFlags(&m->ev[i], hipEventDisableTiming));
+    m->n_ev = 64;
+    return AREAD_OK;
+}
+
+extern "C" void aread_model_destroy(aread_model* m) {
+    if (!m) return;
+    if (m->side) {
+        for (int i = 0; i < m->n_ev; ++i) (void)hipEventDestroy(m->ev[i]);
+        (void)hipStreamDestroy(m->side);
+    }
+    delete m;
+}
 extern "C" int64_t aread_model_param_floats(const aread_model* m) { return m ? m->n_params : -1; }
 extern "C" int64_t aread_model_stat_floats(const aread_model* m) { return m ? m->n_stats : -1; }
 extern "C" int aread_model_n_bn(const aread_model* m) { return m ? m->n_bn : -1; }

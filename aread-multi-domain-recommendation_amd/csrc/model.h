@@ -46,7 +46,12 @@ struct aread_model {
     int gate_off[AREAD_MAX_LEVEL];           // first gate row of level l (l >= 1)
     int ld_ge, ld_gt, ld_h;                  // padded leading dims: MMoE gate logits, tower gate logits, heads
     std::vector<aread_tensor_desc> tensors;
+    // side stream + event pool for fork-join concurrency inside one call (created on first use, per device)
+    mutable hipStream_t side = nullptr;
+    mutable hipEvent_t ev[64] = {};
+    mutable int n_ev = 0;
 };
+int model_streams_init(const aread_model* m);
 
 struct WsLayout {                            // float offsets into the workspace (computed per (B, n_seg))
     int64_t max_rows, n_tiles;

@@ -49,17 +49,20 @@ class DataParallelStep:
 
     def local(self, x, y, masks_dev):
         """graph-capturable: everything that needs no communication"""
-        return self.model.step_local(x, y, self.bufs, masks_dev=masks_dev, with_dense_l2=False)
+        return self.model.step_local(x, y, self.bufs, masks_dev=masks_dev, with_dense_l2=False, presort=self.world == 1)
 
     def exchange_and_scatter(self, x, st):
         m, b = self.model, self.bufs
         if self.world > 1:
             x_all, sr_all, de_all = gather_sparse_grad_inputs(x, st.plan.sample_row, b["de"], self.group)
+            m.step_finish(b)                                        # dense gradients complete
             reduce_dense_grad(b["gdense"], self.group)
+            m.add_dense_l2(b)
+            m.step_scatter(x_all, de_all, sr_all, b["gtable"])
         else:
-            x_all, sr_all, de_all = x, st.plan.sample_row, b["de"]
-        m.add_dense_l2(b)
-        m.step_scatter(x_all, de_all, sr_all, b["gtable"])
+            m.embedding.reduce_sorted(x, b["de"], b["gtable"])      # the sort already ran on the side stream
+            m.step_finish(b)
+            m.add_dense_l2(b)
         torch.add(b["loss"][:1], b["reg"][:1], out=b["total"])
         return b["total"]
 

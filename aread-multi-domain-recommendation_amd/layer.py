@@ -105,6 +105,30 @@ class FeaturesEmbedding(nn.Module):
                                         self.seq_maxlen, self._pool, L.ptr(sample_row), L.ptr(dout), L.ptr(grad),
                                         L.ptr(self._bwd_ws), L.stream()))
 
+    def _ws_for(self, x):
+        B, f_in = x.shape
+        need = L.lib().aread_embed_bwd_ws_bytes(B, f_in, self.embed_dim)
+        if need < 0:
+            raise RuntimeError("aread_embed_bwd_ws_bytes failed")
+        if self._bwd_ws is None or self._bwd_ws.numel() < need or self._bwd_ws.device != x.device:
+            self._bwd_ws = torch.empty(int(need), dtype=torch.uint8, device=x.device)
+        return self._bwd_ws
+
+    def sort_lookups(self, x, sample_row=None):
+        """phase 1 of scatter_grad: depends only on the ids, can run on a side stream."""
+        B, f_in = x.shape
+        L.check(L.lib().aread_embed_bwd_sort(L.ptr(x), B, f_in, L.ptr(self._offsets_dev(x.device)),
+                                             self.embedding_dict.weight.shape[0], self.embed_dim, self.one_hot_field_num,
+                                             self.multi_hot_field_num, self.seq_maxlen, self._pool, L.ptr(sample_row),
+                                             L.ptr(self._ws_for(x)), L.stream()))
+
+    def reduce_sorted(self, x, dout, grad):
+        """phase 2 of scatter_grad: grad[g] += contributions, in the order fixed by sort_lookups."""
+        B, f_in = x.shape
+        seq = self.seq_maxlen if self._pool != 0 else 1
+        L.check(L.lib().aread_embed_bwd_reduce(B, f_in, self.embed_dim, seq, L.ptr(dout), L.ptr(grad), L.ptr(self._ws_for(x)),
+                                               L.stream()))
+
     def forward(self, x, squeeze_dim=False, row_plan=None):
         """x: int32 [B, F_in] on the HIP device -> [B, output_dim0, E] (or [B, output_dim0*E])."""
         if row_plan is None:

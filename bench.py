@@ -32,7 +32,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8192, help="samples per GPU per step")
-    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly (multi-stream) instead of replaying a hipGraph")
+    ap.add_argument("--graph", action="store_true", help="force hipGraph replay (default: time both briefly, keep the faster)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=6)
     ap.add_argument("--dropout", type=float, default=0.2)
@@ -144,6 +145,27 @@ def main():
             step()
         after()
 
+    def quick(n=8):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for i in range(n):
+            run_one(i)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n
+
+    # launch mode: hipGraph replay vs eager launches with fork-join side streams -- keep whichever is faster here
+    if graph is not None and not args.graph:
+        captured = graph
+        quick(3); t_graph = quick()
+        graph = None
+        quick(3); t_eager = quick()
+        if use_dp:
+            tt = torch.tensor([t_graph, t_eager], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_graph, t_eager = float(tt[0]), float(tt[1])
+        log(f"launch mode: graph {t_graph * 1e3:.3f} ms/step, eager multi-stream {t_eager * 1e3:.3f} ms/step")
+        graph = captured if t_graph < t_eager else None
+
     for i in range(args.warmup):
         run_one(i)
     torch.cuda.synchronize()
@@ -179,7 +201,7 @@ def main():
                                "[1368287,7,25,45,11,22356,10], E=32, 17 id columns, experts 4x(256,128,64), towers 3/6/12",
                    "batch_per_gpu": B, "global_batch": B * world, "domain_dist": args.domain_dist,
                    "dropout": args.dropout, "mask_active_frac": 0.7, "optimizer_in_timed_region": False,
-                   "dense_table_l2_in_timed_region": True, "launch": "hipGraph replay" if graph is not None else "eager",
+                   "dense_table_l2_in_timed_region": True, "launch": "hipGraph replay" if graph is not None else "eager, fork-join side streams",
                    "parallelism": f"dp{world}" + (": replicated table, all_gather(ids,dE)+all_reduce(dense grads) over RCCL"
                                                    if use_dp else "")},
         "roofline": roofline, "gather_roofline": gather, "loss": round(loss, 6),

@@ -13,7 +13,10 @@
  *   - all pointers are DEVICE pointers unless the parameter is called *_host; the caller owns
  *     every buffer.  No function allocates, frees, synchronises or copies to the host, so any
  *     call sequence can be captured into a hipGraph.
- *   - `stream` is a hipStream_t passed as void*; kernels are launched on it and nowhere else.
+ *   - `stream` is a hipStream_t passed as void*.  aread_forward/aread_backward additionally fork independent
+ *     work (weight-gradient GEMMs, gate logits, reductions) onto one internal non-blocking side stream and join it
+ *     back before returning (fork-join with events: legal inside stream capture); every other entry point
+ *     launches on `stream` only.
  *   - row-major fp32 tensors, int32 indices (run.py:251-258 keeps ids as torch.int).
  */
 #ifndef AREAD_HIP_H
@@ -90,6 +93,14 @@ int aread_embed_bwd(const int32_t* x, int64_t B, int f_in, const int32_t* offset
                     int64_t n_table_rows, int E, int n_onehot, int n_mh_fields, int seq_len, int pool,
                     const int32_t* sample_row, const float* dout, float* table_grad,
                     void* ws, void* stream);
+
+/* The same in two phases, so that the index sort (which depends only on the ids) can run on another stream
+ * while the dense backward is still producing dout: aread_embed_bwd == sort followed by reduce. */
+int aread_embed_bwd_sort(const int32_t* x, int64_t B, int f_in, const int32_t* offsets,
+                         int64_t n_table_rows, int E, int n_onehot, int n_mh_fields, int seq_len, int pool,
+                         const int32_t* sample_row, void* ws, void* stream);
+int aread_embed_bwd_reduce(int64_t B, int f_in, int E, int seq_len, const float* dout, float* table_grad,
+                           void* ws, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense L2 term of the embedding table.  Replaces the table part of
@@ -182,6 +193,9 @@ typedef struct aread_call {
     const float* y;           /* optional labels [B] (float 0/1): enables the fused loss + its gradient */
     const float* seg_weight;  /* optional [n_seg] weights w_d of the per-domain bagging losses (default 1) */
     float* loss_out;          /* optional out: [1 + n_seg]: sum_d w_d*bag_d, then bag_d per segment */
+    int32_t async_tail;       /* aread_backward: 1 = return with de_out complete on `stream` but the parameter
+                                 gradients still finishing on the model's internal side stream; the caller overlaps
+                                 its own work and then calls aread_join(m, stream) */
 } aread_call;
 
 /* e_in: embedding output in plan order [plan.max_rows][D] (aread_embed_fwd with the plan's row_sample). */
@@ -192,6 +206,8 @@ int aread_forward(const aread_model* m, const aread_call* call_host, const float
  * de_out: [plan.max_rows][D], overwritten with the gradient w.r.t. e_in. */
 int aread_backward(const aread_model* m, const aread_call* call_host, const float* e_in, const float* dprobs,
                    float* grads, float* de_out, void* stream);
+/* Makes `stream` wait for the model's internal side stream (see aread_call.async_tail). */
+int aread_join(const aread_model* m, void* stream);
 /* Dense L2 terms: loss_out[0] (+)= sum_i coef[i]*w[i]^2, grads[i] += 2*coef[i]*w[i] (grads may be NULL).
  * coef: device vector like params (aread_model_l2_coef fills a host copy).
  * loss_out must have room for 257 floats: [0] is the result, [1..256] is scratch for block partials. */
