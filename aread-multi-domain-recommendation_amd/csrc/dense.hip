@@ -220,7 +220,11 @@ extern "C" int aread_forward(const aread_model* m, const aread_call* c, const fl
         for (int l = 0; l < cfg.n_level; ++l)
             for (int j = 0; j < m->towers[l].n_layers; ++j) add(m->towers[l].L[j], x.w.tw[l][j], l);
         all.r = x.r; all.mp = x.mp;
-        LAUNCH(k_bn_running, dim3(cdiv(max_cols, 256), all.n_layers), dim3(256), all);
+        // off the critical path: the statistics buffers are not touched again before the next forward
+        TRY(fork_side(x));
+        hipLaunchKernelGGL(k_bn_running, dim3(cdiv(max_cols, 256), all.n_layers), dim3(256), 0, x.side, all);
+        AR_LAUNCH_CHECK();
+        TRY(join_side(x));
     }
     return AREAD_OK;
 }

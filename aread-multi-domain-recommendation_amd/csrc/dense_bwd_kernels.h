@@ -331,7 +331,13 @@ struct MixLBwdP {
     RowsP r; ModeP mp;
 };
 
+// Block = SUB_ROWS rows of one tile.  dIn and prev rows are staged in LDS with 16-byte coalesced loads, every
+// later access is LDS; phase A (thread per (row, tower)) produces the gate-logit gradients and keeps the
+// renormalised gates in LDS, phase B (thread per (row, source, float4)) produces dprev.
+#define MIX_LDS_FLOATS 4096      // per staged operand: SUB_ROWS * (towers * width) <= 4096 floats
 __global__ __launch_bounds__(256) void k_mixl_bwd(const MixLBwdP p) {
+    __shared__ __attribute__((aligned(16))) float s_din[MIX_LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float s_prev[MIX_LDS_FLOATS];
     __shared__ float s_ah[SUB_ROWS][MAX_TOWER * MAX_TOWER / 2 + 1];
     const int tile = blockIdx.x / SUB, r_lo = (blockIdx.x % SUB) * SUB_ROWS;
     const int seg = p.r.tile_seg[tile];
@@ -339,9 +345,20 @@ __global__ __launch_bounds__(256) void k_mixl_bwd(const MixLBwdP p) {
     const int nvalid = p.r.tile_valid[tile];
     const uint8_t* act = active_level(p.mp, p.level) + seg * MAX_TOWER;
     const uint8_t* mk = p.mp.masks ? p.mp.masks + (size_t)p.mp.seg_dom[seg] * p.mp.edge_count + p.mask_off : nullptr;
+    const int wt = p.n_t * p.w, ws_ = p.n_src * p.w;          // floats per row of dIn / prev
+    const int64_t row0 = (int64_t)tile * TILE_M + r_lo;
+    for (int i = threadIdx.x; i < SUB_ROWS * wt / 4; i += 256) {
+        const int rl = i / (wt / 4), c4 = i - rl * (wt / 4);
+        *(float4*)(s_din + rl * wt + c4 * 4) = *(const float4*)(p.dIn + (row0 + rl) * wt + c4 * 4);
+    }
+    for (int i = threadIdx.x; i < SUB_ROWS * ws_ / 4; i += 256) {
+        const int rl = i / (ws_ / 4), c4 = i - rl * (ws_ / 4);
+        *(float4*)(s_prev + rl * ws_ + c4 * 4) = *(const float4*)(p.prev + (row0 + rl) * ws_ + c4 * 4);
+    }
+    __syncthreads();
     for (int it = threadIdx.x; it < SUB_ROWS * p.n_t; it += 256) {
         const int rl = it / p.n_t, t = it - rl * p.n_t, rr = r_lo + rl;
-        const int64_t row = (int64_t)tile * TILE_M + rr;
+        const int64_t row = row0 + rl;
         const bool on = rr < nvalid && act[t];
         float a[MAX_TOWER], am[MAX_TOWER], ah[MAX_TOWER], dah[MAX_TOWER], S = 1.f;
         float* dgl = p.dglog + row * p.ld_g + p.goff + t * p.n_src;
@@ -350,12 +367,15 @@ __global__ __launch_bounds__(256) void k_mixl_bwd(const MixLBwdP p) {
             continue;
         }
         gate_weights(p.glog + row * p.ld_g + p.goff + t * p.n_src, p.n_src, mk, p.n_t, t, p.mp.mode, a, am, ah, &S);
-        const float* din = p.dIn + row * (p.n_t * p.w) + t * p.w;
-        const float* src = p.prev + row * (p.n_src * p.w);
+        const float* din = s_din + rl * wt + t * p.w;
         float dot_ah = 0.f;
         for (int s = 0; s < p.n_src; ++s) {
+            const float* src = s_prev + rl * ws_ + s * p.w;
             float acc = 0.f;
-            for (int c = 0; c < p.w; ++c) acc += din[c] * src[s * p.w + c];
+            for (int c = 0; c < p.w; c += 4) {
+                const float4 d4 = *(const float4*)(din + c), x4 = *(const float4*)(src + c);
+                acc += d4.x * x4.x + d4.y * x4.y + d4.z * x4.z + d4.w * x4.w;
+            }
             dah[s] = acc;
             dot_ah += acc * ah[s];
             s_ah[rl][t * p.n_src + s] = ah[s];
@@ -369,23 +389,20 @@ __global__ __launch_bounds__(256) void k_mixl_bwd(const MixLBwdP p) {
         for (int s = 0; s < p.n_src; ++s) dgl[s] = a[s] * (da[s] - dot_a);
     }
     __syncthreads();
-    for (int it = threadIdx.x; it < SUB_ROWS * p.n_src; it += 256) {
-        const int rl = it / p.n_src, s = it - rl * p.n_src, rr = r_lo + rl;
-        const int64_t row = (int64_t)tile * TILE_M + rr;
-        float* dst = p.dprev + row * (p.n_src * p.w) + s * p.w;
-        const float* din = p.dIn + row * (p.n_t * p.w);
-        for (int c = 0; c < p.w; c += 4) {
-            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rr < nvalid)
-                for (int t = 0; t < p.n_t; ++t) {
-                    const float wgt = s_ah[rl][t * p.n_src + s];
-                    if (wgt != 0.f) {
-                        const float4 x = *(const float4*)(din + t * p.w + c);
-                        o.x += wgt * x.x; o.y += wgt * x.y; o.z += wgt * x.z; o.w += wgt * x.w;
-                    }
+    const int w4 = p.w / 4;
+    for (int it = threadIdx.x; it < SUB_ROWS * p.n_src * w4; it += 256) {
+        const int rl = it / (p.n_src * w4), rem = it - rl * (p.n_src * w4);
+        const int s = rem / w4, c = (rem - s * w4) * 4;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r_lo + rl < nvalid)
+            for (int t = 0; t < p.n_t; ++t) {
+                const float wgt = s_ah[rl][t * p.n_src + s];
+                if (wgt != 0.f) {
+                    const float4 x = *(const float4*)(s_din + rl * wt + t * p.w + c);
+                    o.x += wgt * x.x; o.y += wgt * x.y; o.z += wgt * x.z; o.w += wgt * x.w;
                 }
-            *(float4*)(dst + c) = o;
-        }
+            }
+        *(float4*)(p.dprev + (row0 + rl) * ws_ + s * p.w + c) = o;
     }
 }
 
@@ -397,15 +414,28 @@ struct Mix0BwdP {
 };
 
 __global__ __launch_bounds__(256) void k_mix0_bwd(const Mix0BwdP p) {
+    __shared__ __attribute__((aligned(16))) float s_du[MIX_LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float s_x[2 * MIX_LDS_FLOATS];
     __shared__ float s_pi[SUB_ROWS][MAX_TOWER * 8 + 1];
     const int tile = blockIdx.x / SUB, r_lo = (blockIdx.x % SUB) * SUB_ROWS;
     const int seg = p.r.tile_seg[tile];
     if (seg < 0) return;
     const int nvalid = p.r.tile_valid[tile];
     const uint8_t* act = active_level(p.mp, 0) + seg * MAX_TOWER;
+    const int wu = p.n_t * p.h, wx = p.n_exp * p.h;
+    const int64_t row0 = (int64_t)tile * TILE_M + r_lo;
+    for (int i = threadIdx.x; i < SUB_ROWS * wu / 4; i += 256) {
+        const int rl = i / (wu / 4), c4 = i - rl * (wu / 4);
+        *(float4*)(s_du + rl * wu + c4 * 4) = *(const float4*)(p.dU + (row0 + rl) * wu + c4 * 4);
+    }
+    for (int i = threadIdx.x; i < SUB_ROWS * wx / 4; i += 256) {
+        const int rl = i / (wx / 4), c4 = i - rl * (wx / 4);
+        *(float4*)(s_x + rl * wx + c4 * 4) = *(const float4*)(p.X + (row0 + rl) * wx + c4 * 4);
+    }
+    __syncthreads();
     for (int it = threadIdx.x; it < SUB_ROWS * p.n_t; it += 256) {
         const int rl = it / p.n_t, t = it - rl * p.n_t, rr = r_lo + rl;
-        const int64_t row = (int64_t)tile * TILE_M + rr;
+        const int64_t row = row0 + rl;
         float* dgl = p.dglog + row * p.ld_g + t * p.n_exp;
         if (!(rr < nvalid && act[t])) {
             for (int k = 0; k < p.n_exp; ++k) { dgl[k] = 0.f; s_pi[rl][t * p.n_exp + k] = 0.f; }
@@ -417,13 +447,16 @@ __global__ __launch_bounds__(256) void k_mix0_bwd(const Mix0BwdP p) {
         for (int k = 1; k < p.n_exp; ++k) mx = fmaxf(mx, gl[k]);
         float den = 0.f;
         for (int k = 0; k < p.n_exp; ++k) { pi[k] = __expf(gl[k] - mx); den += pi[k]; }
-        const float* du = p.dU + row * (p.n_t * p.h) + t * p.h;
+        const float* du = s_du + rl * wu + t * p.h;
         float dot = 0.f;
         for (int k = 0; k < p.n_exp; ++k) {
             pi[k] /= den;
-            const float* x = p.X + row * (p.n_exp * p.h) + k * p.h;
+            const float* xk = s_x + rl * wx + k * p.h;
             float acc = 0.f;
-            for (int c = 0; c < p.h; ++c) acc += du[c] * x[c];
+            for (int c = 0; c < p.h; c += 4) {
+                const float4 d4 = *(const float4*)(du + c), x4 = *(const float4*)(xk + c);
+                acc += d4.x * x4.x + d4.y * x4.y + d4.z * x4.z + d4.w * x4.w;
+            }
             dpi[k] = acc;
             dot += acc * pi[k];
             s_pi[rl][t * p.n_exp + k] = pi[k];
@@ -433,19 +466,18 @@ __global__ __launch_bounds__(256) void k_mix0_bwd(const Mix0BwdP p) {
     __syncthreads();
     const int h4 = p.h >> 2;
     for (int it = threadIdx.x; it < SUB_ROWS * p.n_exp * h4; it += 256) {
-        const int rl = it / (p.n_exp * h4), rem = it - rl * (p.n_exp * h4), rr = r_lo + rl;
+        const int rl = it / (p.n_exp * h4), rem = it - rl * (p.n_exp * h4);
         const int k = rem / h4, c = (rem - k * h4) * 4;
-        const int64_t row = (int64_t)tile * TILE_M + rr;
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (rr < nvalid)
+        if (r_lo + rl < nvalid)
             for (int t = 0; t < p.n_t; ++t) {
                 const float wgt = s_pi[rl][t * p.n_exp + k];
                 if (wgt != 0.f) {
-                    const float4 x = *(const float4*)(p.dU + row * (p.n_t * p.h) + t * p.h + c);
+                    const float4 x = *(const float4*)(s_du + rl * wu + t * p.h + c);
                     o.x += wgt * x.x; o.y += wgt * x.y; o.z += wgt * x.z; o.w += wgt * x.w;
                 }
             }
-        *(float4*)(p.dX + row * (p.n_exp * p.h) + k * p.h + c) = o;
+        *(float4*)(p.dX + (row0 + rl) * wx + k * p.h + c) = o;
     }
 }
 

@@ -49,28 +49,35 @@ struct MaskPrepP {
 
 __global__ __launch_bounds__(256) void k_mask_prep(const MaskPrepP p) {
     const int tid = threadIdx.x;
+    int n_tot = 0;
+    for (int l = 0; l < p.n_level; ++l) n_tot += p.n_tower[l];
     for (int i = tid; i < AREAD_MAX_LEVEL * MAX_SEG * MAX_TOWER; i += 256) p.active[i] = 0;
-    __syncthreads();
     for (int s = tid; s < MAX_SEG; s += 256) {
         int dom = p.n_seg == 1 ? p.domain : s;
-        if (dom < 0) dom = 0;
-        if (dom >= p.n_domain) dom = p.n_domain - 1;
+        dom = dom < 0 ? 0 : (dom >= p.n_domain ? p.n_domain - 1 : dom);
         p.seg_dom[s] = dom;
+    }
+    __syncthreads();
+    // one thread per (segment, tower): is the tower fed by any edge of the segment's domain mask?
+    for (int i = tid; i < p.n_seg * n_tot; i += 256) {
+        const int s = i / n_tot;
+        int t = i - s * n_tot, l = 0;
+        while (t >= p.n_tower[l]) { t -= p.n_tower[l]; ++l; }
+        int a = 1;
+        if (p.mode == 0) {
+            const uint8_t* mk = p.masks + (size_t)p.seg_dom[s] * p.edge_count + p.mask_off[l];
+            const int n_src = l == 0 ? 1 : p.n_tower[l - 1];
+            a = 0;
+            for (int src = 0; src < n_src; ++src) a |= mk[src * p.n_tower[l] + t] ? 1 : 0;
+        }
+        p.active[((size_t)l * MAX_SEG + s) * MAX_TOWER + t] = (uint8_t)a;
+    }
+    __syncthreads();
+    for (int s = tid; s < MAX_SEG; s += 256) {
         int k = 0, n0 = 0;
         if (s < p.n_seg) {
-            const uint8_t* mk = p.masks ? p.masks + (size_t)dom * p.edge_count : nullptr;
-            for (int l = 0; l < p.n_level; ++l) {
-                const int n_src = l == 0 ? 1 : p.n_tower[l - 1];
-                for (int t = 0; t < p.n_tower[l]; ++t) {
-                    int a = 0;
-                    if (p.mode == 1) a = 1;
-                    else
-                        for (int src = 0; src < n_src; ++src) a |= mk[p.mask_off[l] + src * p.n_tower[l] + t] ? 1 : 0;
-                    p.active[((size_t)l * MAX_SEG + s) * MAX_TOWER + t] = (uint8_t)a;
-                    if (l == 0) n0 += a;
-                    if (l == p.n_level - 1) k += a;
-                }
-            }
+            for (int t = 0; t < p.n_tower[0]; ++t) n0 += p.active[(size_t)s * MAX_TOWER + t];
+            for (int t = 0; t < p.n_tower[p.n_level - 1]; ++t) k += p.active[((size_t)(p.n_level - 1) * MAX_SEG + s) * MAX_TOWER + t];
         }
         p.kact[s] = k;
         p.n0act[s] = n0;

@@ -58,6 +58,9 @@ struct TileLoader {
     static constexpr int ROW_STEP = KC ? GEMM_PITCH : 1;     // +1 row
     static constexpr int K_STEP = KC ? 1 : PITCH_R;          // +1 k
 
+    // FULL: the tile lies completely inside the operand (no row / k guards): straight-line 16-byte loads that the
+    // compiler can issue back to back and wait for once.  Otherwise every element is guarded (edges, K tails).
+    template <bool FULL>
     __device__ __forceinline__ void load(const float* __restrict__ base, int64_t ld, int r0, int r_end, int k0,
                                          int k_end) {
         const int tid = threadIdx.x;
@@ -67,10 +70,11 @@ struct TileLoader {
             float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
             if (KC) {
                 const int row = idx >> 3, kq = idx & 7;                 // 8 float4 per row of BK=32
-                if (row < ROWS) {
+                if (ROWS * 8 % GEMM_THREADS == 0 || row < ROWS) {
                     const int r = r0 + row, k = k0 + 4 * kq;
-                    if (r < r_end) {
-                        const float* ptr = base + (int64_t)r * ld + k;
+                    const float* ptr = base + (int64_t)r * ld + k;
+                    if (FULL) t = *(const float4*)ptr;
+                    else if (r < r_end) {
                         if (k + 3 < k_end) t = *(const float4*)ptr;
                         else {
                             if (k < k_end) t.x = ptr[0];
@@ -82,10 +86,11 @@ struct TileLoader {
             } else {
                 constexpr int Q = ROWS / 4;                              // float4 per k-row
                 const int krow = idx / Q, mq = idx - krow * Q;
-                if (krow < GEMM_BK) {
+                if ((Q * GEMM_BK) % GEMM_THREADS == 0 || krow < GEMM_BK) {
                     const int k = k0 + krow, r = r0 + 4 * mq;
-                    if (k < k_end) {
-                        const float* ptr = base + (int64_t)k * ld + r;
+                    const float* ptr = base + (int64_t)k * ld + r;
+                    if (FULL) t = *(const float4*)ptr;
+                    else if (k < k_end) {
                         if (r + 3 < r_end) t = *(const float4*)ptr;
                         else {
                             if (r < r_end) t.x = ptr[0];
@@ -131,11 +136,23 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm(const GemmP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = blockIdx.z / p.k_split, ks = blockIdx.z - g * p.k_split;
-    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    // XCD-aware tile mapping: workgroups are dealt round-robin over the 8 XCDs (each with a private L2), so give
+    // all column tiles of one row tile to the same XCD -- the A row tile is then fetched into one L2, not eight.
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const int nx = gridDim.x, ny8 = (gridDim.y / 8) * 8;
+        const int id = blockIdx.x + nx * blockIdx.y;
+        if (id < nx * ny8) {
+            const int xcd = id & 7, slot = id >> 3;
+            bx = slot % nx;
+            by = (slot / nx) * 8 + xcd;
+        }
+    }
+    const int m0 = by * TM, n0 = bx * TN;
 
     int seg = 0;
     if (p.gate_axis == 1) {
-        seg = p.tile_seg[blockIdx.y];
+        seg = p.tile_seg[by];
         if (seg < 0) return;
         if (p.active && !p.active[seg * p.active_ld + g]) return;
     }
@@ -162,21 +179,25 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm(const GemmP p) {
 
     LA la;
     LB lb;
+    const bool full_mn = (m0 + TM <= p.M) && (n0 + TN <= p.N);
+    auto load_tiles = [&](int kk0) {
+        if (full_mn && kk0 + GEMM_BK <= k_end) {               // wave-uniform
+            la.template load<true>(Ag, p.lda, m0, p.M, kk0, k_end);
+            lb.template load<true>(Bg, p.ldb, n0, p.N, kk0, k_end);
+        } else {
+            la.template load<false>(Ag, p.lda, m0, p.M, kk0, k_end);
+            lb.template load<false>(Bg, p.ldb, n0, p.N, kk0, k_end);
+        }
+    };
     int k0 = next_live(k_begin);
-    if (k0 < k_end) {
-        la.load(Ag, p.lda, m0, p.M, k0, k_end);
-        lb.load(Bg, p.ldb, n0, p.N, k0, k_end);
-    }
+    if (k0 < k_end) load_tiles(k0);
     const int fr = lane & 15, fk = lane >> 4;
     while (k0 < k_end) {
         la.store(As);
         lb.store(Bs);
         __syncthreads();
         const int kn = next_live(k0 + GEMM_BK);
-        if (kn < k_end) {
-            la.load(Ag, p.lda, m0, p.M, kn, k_end);
-            lb.load(Bg, p.ldb, n0, p.N, kn, k_end);
-        }
+        if (kn < k_end) load_tiles(kn);
         const float* ap = As + LA::frag_offset(wave * 16 + fr, fk);
         const float* bp = Bs + LB::frag_offset(fr, fk);
 #pragma unroll
@@ -212,7 +233,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm(const GemmP p) {
         }
     }
     if (p.stat_part) {
-        const int nvalid = p.tile_valid[blockIdx.y];
+        const int nvalid = p.tile_valid[by];
         // pass 1: column sums over valid rows
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -252,7 +273,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm(const GemmP p) {
                 const int c = i * 16 + lane, n = n0 + c;
                 if (n < p.N) {
                     const float m2 = (s_red[0][c] + s_red[1][c]) + (s_red[2][c] + s_red[3][c]);
-                    float* o = p.stat_part + ((int64_t)blockIdx.y * p.stat_ld + (int64_t)g * p.N + n) * 2;
+                    float* o = p.stat_part + ((int64_t)by * p.stat_ld + (int64_t)g * p.N + n) * 2;
                     o[0] = mean[i];
                     o[1] = m2;
                 }

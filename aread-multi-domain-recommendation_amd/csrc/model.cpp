@@ -70,6 +70,13 @@ extern "C" int aread_model_create(const aread_model_cfg* c, aread_model** out) {
             AR_CHECK_ARG(c->tower_dims[l][j] > 0 && c->tower_dims[l][j] % 4 == 0, "tower_dims[%d][%d]=%d must be a positive multiple of 4",
                          l, j, c->tower_dims[l][j]);
     }
+    for (int l = 0; l < c->n_level; ++l) {
+        // row-local mix kernels stage 16 rows x (towers x width) floats per operand in LDS
+        const int w_in = l == 0 ? c->expert_dims[c->n_expert_layers - 1] : c->tower_dims[l - 1][c->n_tower_layers - 1];
+        AR_CHECK_ARG(16 * c->n_tower[l] * w_in <= 4096, "level %d: n_tower*input_width = %d exceeds 256", l, c->n_tower[l] * w_in);
+        if (l > 0) AR_CHECK_ARG(c->n_tower[l] * c->n_tower[l - 1] <= 128, "level %d: too many gate edges", l);
+    }
+    AR_CHECK_ARG(16 * c->n_expert * c->expert_dims[c->n_expert_layers - 1] <= 8192, "n_expert*expert_out exceeds 512");
     aread_model* m = new aread_model();
     m->cfg = *c;
     m->E = c->embed_dim;

@@ -190,7 +190,8 @@ def main():
     value = world * B * args.steps / dt
 
     # ---- roofline of the dominant kernel: the dense-L2 table sweep (read table, write dense gradient) ----
-    roofline = measure_l2_kernel(model, bufs, L)
+    roofline = measure_gemm_kernel(model, bufs, L, B)           # dominant kernel by rocprof share (profiles/)
+    l2pass = measure_l2_kernel(model, bufs, L)
     gather = measure_gather_kernel(model, xs, bufs, L)
 
     out = {
@@ -204,7 +205,7 @@ def main():
                    "dense_table_l2_in_timed_region": True, "launch": "hipGraph replay" if graph is not None else "eager, fork-join side streams",
                    "parallelism": f"dp{world}" + (": replicated table, all_gather(ids,dE)+all_reduce(dense grads) over RCCL"
                                                    if use_dp else "")},
-        "roofline": roofline, "gather_roofline": gather, "loss": round(loss, 6),
+        "roofline": roofline, "l2_table_roofline": l2pass, "gather_roofline": gather, "loss": round(loss, 6),
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(O, spec, P, masks, batches, args)
@@ -228,6 +229,40 @@ def _time_kernel(fn, iters=30, warm=3):
     return e0.elapsed_time(e1) / iters * 1e-3     # seconds
 
 
+def _pmc_traffic(kernel):
+    """HBM bytes per launch from the committed rocprofv3 --pmc summary (profiles/), if present."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_roofline_kernels.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
+    except Exception:                                                # noqa: BLE001
+        return None
+
+
+def measure_gemm_kernel(model, bufs, L, B):
+    """Expert layer 1 forward: H1[rows,1024] = E[rows,288] . W1[1024,288]^T + b  (k_gemm<8,true,true>), the single most
+    expensive kernel of the step.  Algorithmic FLOPs = 2 * 288 * 1024 per SAMPLE x B samples; the launch
+    itself runs on the tile-padded row count."""
+    rows, D = bufs["e"].shape
+    h1 = model.expert_dims[0] * int(model._cfg.n_expert)
+    w_off = next(off for name, kind, off, shape, _ in model._tensors if name == "mmoe_experts.0.layers.0.weight")
+    b_off = next(off for name, kind, off, shape, _ in model._tensors if name == "mmoe_experts.0.layers.0.bias")
+    W = model.dense.data[w_off:w_off + h1 * D]
+    bias = model.dense.data[b_off:b_off + h1]
+    out = torch.empty((rows, h1), device=W.device)
+    A = bufs["e"]
+    fn = lambda: L.check(L.lib().aread_gemm(L.ptr(A), D, 0, 1, L.ptr(W), D, 0, 1, L.ptr(out), h1, 0, L.ptr(bias), 0, rows, h1, D,
+                                            1, 0, L.stream()))
+    t = _time_kernel(fn)
+    alg = 2.0 * D * h1 * B
+    ach = alg / t / 1e12
+    return {"kernel": "k_gemm<8,true,true> (expert layer 1 forward)", "bound": "mfma", "achieved": round(ach, 2),
+            "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4),
+            "traffic": _pmc_traffic("k_gemm<8,true,true>"), "traffic_source": "profiles/r01_pmc_roofline_kernels.json",
+            "algorithmic_flops_per_launch": alg, "executed_flops_per_launch": 2.0 * D * h1 * rows, "avg_launch_us": round(t * 1e6, 2),
+            "mfma": "v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate)"}
+
+
 def measure_l2_kernel(model, bufs, L):
     table = model.embedding.embedding_dict.weight
     n = table.numel()
@@ -238,7 +273,7 @@ def measure_l2_kernel(model, bufs, L):
     alg = 2.0 * n * 4                               # read every weight once, write every gradient once
     ach = alg / t / 1e9
     return {"kernel": "k_l2_table", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": alg,
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic("k_l2_table"), "algorithmic_bytes_per_launch": alg,
             "avg_launch_us": round(t * 1e6, 2)}
 
 
@@ -257,6 +292,7 @@ def measure_gather_kernel(model, xs, bufs, L):
     ach = per_sample * B / t / 1e9
     return {"kernel": "k_embed_fwd", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4), "read_stream_frac": round(read_stream * B / t / 1e9 / HBM_PEAK_GBS, 4),
+            "traffic": _pmc_traffic("k_embed_fwd"),
             "algorithmic_bytes_per_launch": per_sample * B, "avg_launch_us": round(t * 1e6, 2)}
 
 

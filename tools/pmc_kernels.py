@@ -1,0 +1,28 @@
+"""Run the three roofline kernels a few times each (for rocprofv3 --pmc passes): expert-L1 forward GEMM at the
+bench shape, the table L2 pass and the embedding gather."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import aread_amd
+from aread_amd import _lib as L
+from oracle import aread_oracle as O
+from tools import synth
+
+spec = O.amazon_spec()
+rng = np.random.default_rng(0)
+M, N, K = 9728, 1024, 288
+A = torch.randn(M * K, device="cuda"); B = torch.randn(N * K, device="cuda"); C = torch.empty(M * N, device="cuda")
+R = spec.rows
+table = torch.randn(R * 32, device="cuda") * 0.5
+grad = torch.empty_like(table)
+part = torch.empty(L.lib().aread_l2_partials(), device="cuda")
+x, _ = synth.amazon_batch(spec, rng, 8192)
+xs = torch.from_numpy(x).cuda()
+off = torch.from_numpy(spec.offsets().astype(np.int32)).cuda()
+out = torch.empty(8192 * 9 * 32, device="cuda")
+for _ in range(5):
+    L.check(L.lib().aread_gemm(L.ptr(A), K, M * K, 1, L.ptr(B), K, N * K, 1, L.ptr(C), N, M * N, None, 0, M, N, K, 1, 0, L.stream()))
+    L.check(L.lib().aread_l2_table(L.ptr(table), table.numel(), 1e-5, 1.0, L.ptr(grad), L.ptr(part), L.stream()))
+    L.check(L.lib().aread_embed_fwd(L.ptr(xs), 8192, 17, L.ptr(off), L.ptr(table), R, 32, 7, 2, 5, 2, None, 8192, L.ptr(out), None,
+                                    L.stream()))
+torch.cuda.synchronize()
