@@ -30,7 +30,8 @@ class ModelCfg(C.Structure):
                 ("n_expert", C.c_int32), ("n_expert_layers", C.c_int32), ("expert_dims", C.c_int32 * MAX_LAYER),
                 ("n_level", C.c_int32), ("n_tower", C.c_int32 * MAX_LEVEL), ("n_tower_layers", C.c_int32),
                 ("tower_dims", (C.c_int32 * MAX_LAYER) * MAX_LEVEL), ("n_cross", C.c_int32), ("n_domain", C.c_int32),
-                ("dropout", C.c_float), ("l2_linear", C.c_float), ("l2_dnn", C.c_float), ("l2_cross", C.c_float)]
+                ("dropout", C.c_float), ("l2_linear", C.c_float), ("l2_dnn", C.c_float), ("l2_cross", C.c_float),
+                ("precision", C.c_int32)]
 
 
 class TensorDesc(C.Structure):
@@ -191,6 +192,12 @@ class AREAD(HempMixin, nn.Module):
                 cfg.tower_dims[l][j] = v
         cfg.n_cross, cfg.n_domain, cfg.dropout = int(config.n_cross_layers), n_domain, self.dropout
         cfg.l2_linear, cfg.l2_dnn, cfg.l2_cross = self.l2_reg_linear, self.l2_reg_dnn, self.l2_reg_cross
+        # extension knob (not in the reference's config.py): 'f32' = exact fp32 MFMA everywhere (default),
+        # 'bf16x3' = split-bf16 forward/dgrad GEMMs in the expert and tower layers
+        self.precision = getattr(config, "aread_precision", "f32")
+        if self.precision not in ("f32", "bf16x3"):
+            raise ValueError("config.aread_precision must be 'f32' or 'bf16x3'")
+        cfg.precision = 1 if self.precision == "bf16x3" else 0
         self._cfg = cfg
         h = C.c_void_p()
         L.check(L.lib().aread_model_create(C.byref(cfg), C.byref(h)))

@@ -97,7 +97,8 @@ static int layer_fwd(Ctx& x, const LayerL& L, const LayerWs& lw, const float* in
     g.gate_axis = 1; g.tile_seg = x.r.tile_seg; g.tile_valid = x.r.tile_valid;
     g.active = (level >= 0 && g.G > 1) ? level_active(x, level) : nullptr; g.active_ld = MAX_TOWER;
     if (x.c->train) { g.stat_part = x.ws + lw.part; g.stat_ld = L.ncols; }
-    TRY(launch_gemm(g, true, true, x.st));
+    if (x.m->cfg.precision == 1) TRY(launch_gemm_bf3(g, x.st));
+    else TRY(launch_gemm(g, true, true, x.st));
     BnActP a = {};
     a.H = x.ws + lw.H; a.Act = x.ws + lw.Act; a.part = x.ws + lw.part;
     a.mean = x.ws + lw.mean; a.rstd = x.ws + lw.rstd; a.var = x.ws + lw.var;
@@ -156,6 +157,22 @@ extern "C" int aread_forward(const aread_model* m, const aread_call* c, const fl
     {
         const hipStream_t main_st = x.st;
         x.st = x.side;
+        if (c->train && cfg.precision == 1) {          // transposed weights for the split-bf16 dgrad of the backward
+            TransAllP ta = {};
+            int64_t mx = 0;
+            auto add = [&](const LayerL& L, const LayerWs& lw) {
+                const bool sh = (L.in_gs == 0 && L.G > 1) || L.G == 1;
+                TransOne& d = ta.d[ta.n++];
+                d.W = P + L.w; d.WT = ws + lw.wT; d.G = sh ? 1 : L.G; d.out = sh ? L.ncols : L.out_dim; d.in = L.in_dim;
+                if ((int64_t)L.ncols * L.in_dim > mx) mx = (int64_t)L.ncols * L.in_dim;
+            };
+            for (int j = 0; j < m->experts.n_layers; ++j) add(m->experts.L[j], x.w.ex[j]);
+            for (int l = 0; l < cfg.n_level; ++l)
+                for (int j = 0; j < m->towers[l].n_layers; ++j) add(m->towers[l].L[j], x.w.tw[l][j]);
+            int bx = cdiv(mx, 256);
+            if (bx > 256) bx = 256;
+            LAUNCH(k_transpose_weights, dim3(bx, ta.n), dim3(256), ta);
+        }
         RowwiseP rw = {};
         rw.e = e_in; rw.cn = ws + x.w.cn; rw.lin = ws + x.w.lin; rw.xw = ws + x.w.xw; rw.q = ws + x.w.q; rw.grp = ws + x.w.grp;
         rw.lin_w = P + m->lin_w; rw.lin_b = P + m->lin_b; rw.cn_w = P + m->cn_w; rw.cn_b = P + m->cn_b;
@@ -302,7 +319,12 @@ static int layer_bwd(Ctx& x, const LayerL& L, const LayerWs& lw, const float* in
         g.M = (int)x.rows; g.N = L.in_dim; g.K = L.out_dim; g.G = L.G; g.accumulate = accumulate_d_in;
         if (shared || L.G == 1) { g.K = L.ncols; g.G = 1; g.a_gs = 0; g.b_gs = 0; g.c_gs = 0; }
         g.gate_axis = 1; g.tile_seg = x.r.tile_seg; g.tile_valid = x.r.tile_valid;
-        TRY(launch_gemm(g, true, false, x.st));   // inactive towers contribute dH = 0
+        if (x.m->cfg.precision == 1) {              // k-contiguous B from the transposed weight copy [g][in][out]
+            g.B = x.ws + lw.wT;
+            g.ldb = (shared || L.G == 1) ? L.ncols : L.out_dim;
+            g.b_gs = (shared || L.G == 1) ? 0 : (int64_t)L.in_dim * L.out_dim;
+            TRY(launch_gemm_bf3(g, x.st));
+        } else TRY(launch_gemm(g, true, false, x.st));   // inactive towers contribute dH = 0
     }
     // wgrad: dW = dH^T in
     if (shared) TRY(wgrad(x, d, L.ncols, 0, in, L.in_ld, 0, 1, L.ncols, L.in_dim, grads + L.w, L.in_dim, 0, nullptr, slab_off));

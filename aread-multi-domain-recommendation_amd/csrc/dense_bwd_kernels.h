@@ -77,6 +77,20 @@ __global__ __launch_bounds__(256) void k_colsum(const float* X, int64_t ldx, int
     }
 }
 
+// batched weight transposes: WT[g][i][o] = W[g][o][i]   (grid.y = layer; weights are small)
+struct TransOne { const float* W; float* WT; int G, out, in; };
+struct TransAllP { int n; TransOne d[MAX_BN_LAYERS_DECL]; };
+__global__ __launch_bounds__(256) void k_transpose_weights(const TransAllP a) {
+    const TransOne& p = a.d[blockIdx.y];
+    const int64_t n = (int64_t)p.G * p.out * p.in;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * 256) {
+        const int o = (int)(idx % p.out);
+        const int64_t r = idx / p.out;
+        const int i = (int)(r % p.in), g = (int)(r / p.in);
+        p.WT[idx] = p.W[((int64_t)g * p.out + o) * p.in + i];
+    }
+}
+
 // batched split-K reduction: for every wgrad d, out[g][m][n] = sum_ks slab[ks][g][m][n]  (grid.y = d)
 struct SplitKOne { const float* slab; float* out; int k_split, G, M, N; int64_t ldo, o_gs; };
 #define MAX_WGRADS 24

@@ -125,6 +125,80 @@ struct TileLoader {
     }
 };
 
+// ---- epilogue shared by the fp32 and the split-bf16 kernels ----------------------------------------------
+// C/D layout of every 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg.
+template <int NI>
+__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[NI], int g, int ks, int m0, int n0, int by,
+                                              float (*s_red)[16 * NI]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col_in = lane & 15, row_base = wave * 16 + (lane >> 4) * 4;
+    float* Cg = p.C + (int64_t)g * p.c_gs + (int64_t)ks * p.c_ks;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int n = n0 + i * 16 + col_in;
+        if (n < p.N) {
+            const float bv = p.bias ? p.bias[(int64_t)g * p.bias_gs + n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[i][r] += bv;
+                const int m = m0 + row_base + r;
+                if (m < p.M) {
+                    float* c = Cg + (int64_t)m * p.ldc + n;
+                    *c = p.accumulate ? *c + acc[i][r] : acc[i][r];
+                }
+            }
+        }
+    }
+    if (p.stat_part) {
+        const int nvalid = p.tile_valid[by];
+        // pass 1: column sums over valid rows
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s += (row_base + r < nvalid) ? acc[i][r] : 0.f;
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (lane < 16) s_red[wave][i * 16 + lane] = s;
+        }
+        __syncthreads();
+        float mean[NI];
+        const float inv = 1.0f / (float)nvalid;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int c = i * 16 + col_in;
+            mean[i] = ((s_red[0][c] + s_red[1][c]) + (s_red[2][c] + s_red[3][c])) * inv;
+        }
+        __syncthreads();
+        // pass 2: centred sum of squares
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = acc[i][r] - mean[i];
+                s += (row_base + r < nvalid) ? d * d : 0.f;
+            }
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (lane < 16) s_red[wave][i * 16 + lane] = s;
+        }
+        __syncthreads();
+        if (wave == 0 && lane < 16) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int c = i * 16 + lane, n = n0 + c;
+                if (n < p.N) {
+                    const float m2 = (s_red[0][c] + s_red[1][c]) + (s_red[2][c] + s_red[3][c]);
+                    float* o = p.stat_part + ((int64_t)by * p.stat_ld + (int64_t)g * p.N + n) * 2;
+                    o[0] = mean[i];
+                    o[1] = m2;
+                }
+            }
+        }
+    }
+}
+
 template <int NI, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(GEMM_THREADS) void k_gemm(const GemmP p) {
     constexpr int TM = 64, TN = 16 * NI;
@@ -213,73 +287,139 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm(const GemmP p) {
         k0 = kn;
     }
 
-    // ---- epilogue: C/D layout col = lane&15, row = (lane>>4)*4 + reg -------------------------------
-    const int col_in = lane & 15, row_base = wave * 16 + (lane >> 4) * 4;
-    float* Cg = p.C + (int64_t)g * p.c_gs + (int64_t)ks * p.c_ks;
+    gemm_epilogue<NI>(p, acc, g, ks, m0, n0, by, s_red);
+}
+
+// ================================================================================================
+// split-bf16 ("bf16x3") kernel: C (+)= A B^T with both operands k-contiguous fp32 in memory.
+// Every fp32 value x is split while it is staged into LDS: hi = bf16(x), lo = bf16(x - hi); the product is
+// formed as hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (the lo*lo term,
+// 2^-16 relative, is dropped).  Relative error of a dot product ~1e-6: inside the path's 1e-4 logit tolerance,
+// at 3/16 of the matrix-pipe time of the fp32 MFMA.  Same tile shape, gating and epilogue as k_gemm.
+// LDS images: [rows][32 bf16 + 8 pad] for hi and lo (80-byte rows: the 16-byte fragment reads of 16 rows
+// start on 16 different 4-bank groups).
+// ================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#define BF3_PITCH 40        // bf16 elements per LDS row
+
+template <int ROWS>
+struct Bf3Loader {
+    static constexpr int F4 = (ROWS * GEMM_BK / 4 + GEMM_THREADS - 1) / GEMM_THREADS;
+    float4 v[F4];
+
+    template <bool FULL>
+    __device__ __forceinline__ void load(const float* __restrict__ base, int64_t ld, int r0, int r_end, int k0, int k_end) {
+        const int tid = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int n = n0 + i * 16 + col_in;
-        if (n < p.N) {
-            const float bv = p.bias ? p.bias[(int64_t)g * p.bias_gs + n] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                acc[i][r] += bv;
-                const int m = m0 + row_base + r;
-                if (m < p.M) {
-                    float* c = Cg + (int64_t)m * p.ldc + n;
-                    *c = p.accumulate ? *c + acc[i][r] : acc[i][r];
+        for (int p = 0; p < F4; ++p) {
+            const int idx = tid + p * GEMM_THREADS;
+            const int row = idx >> 3, kq = idx & 7;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ROWS * 8 % GEMM_THREADS == 0 || row < ROWS) {
+                const int r = r0 + row, k = k0 + 4 * kq;
+                const float* ptr = base + (int64_t)r * ld + k;
+                if (FULL) t = *(const float4*)ptr;
+                else if (r < r_end) {
+                    if (k + 3 < k_end) t = *(const float4*)ptr;
+                    else {
+                        if (k < k_end) t.x = ptr[0];
+                        if (k + 1 < k_end) t.y = ptr[1];
+                        if (k + 2 < k_end) t.z = ptr[2];
+                    }
                 }
+            }
+            v[p] = t;
+        }
+    }
+
+    __device__ __forceinline__ void store(__bf16* __restrict__ hi, __bf16* __restrict__ lo) const {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int p = 0; p < F4; ++p) {
+            const int idx = tid + p * GEMM_THREADS;
+            const int row = idx >> 3, kq = idx & 7;
+            if (ROWS * 8 % GEMM_THREADS == 0 || row < ROWS) {
+                const float x[4] = {v[p].x, v[p].y, v[p].z, v[p].w};
+                bf16x4 h, l;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    h[i] = (__bf16)x[i];
+                    l[i] = (__bf16)(x[i] - (float)h[i]);
+                }
+                *(bf16x4*)(hi + row * BF3_PITCH + 4 * kq) = h;
+                *(bf16x4*)(lo + row * BF3_PITCH + 4 * kq) = l;
             }
         }
     }
-    if (p.stat_part) {
-        const int nvalid = p.tile_valid[by];
-        // pass 1: column sums over valid rows
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            float s = 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s += (row_base + r < nvalid) ? acc[i][r] : 0.f;
-            s += __shfl_xor(s, 16);
-            s += __shfl_xor(s, 32);
-            if (lane < 16) s_red[wave][i * 16 + lane] = s;
-        }
-        __syncthreads();
-        float mean[NI];
-        const float inv = 1.0f / (float)nvalid;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int c = i * 16 + col_in;
-            mean[i] = ((s_red[0][c] + s_red[1][c]) + (s_red[2][c] + s_red[3][c])) * inv;
-        }
-        __syncthreads();
-        // pass 2: centred sum of squares
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            float s = 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float d = acc[i][r] - mean[i];
-                s += (row_base + r < nvalid) ? d * d : 0.f;
-            }
-            s += __shfl_xor(s, 16);
-            s += __shfl_xor(s, 32);
-            if (lane < 16) s_red[wave][i * 16 + lane] = s;
-        }
-        __syncthreads();
-        if (wave == 0 && lane < 16) {
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int c = i * 16 + lane, n = n0 + c;
-                if (n < p.N) {
-                    const float m2 = (s_red[0][c] + s_red[1][c]) + (s_red[2][c] + s_red[3][c]);
-                    float* o = p.stat_part + ((int64_t)by * p.stat_ld + (int64_t)g * p.N + n) * 2;
-                    o[0] = mean[i];
-                    o[1] = m2;
-                }
-            }
+};
+
+template <int NI>
+__global__ __launch_bounds__(GEMM_THREADS) void k_gemm_bf3(const GemmP p) {
+    constexpr int TM = 64, TN = 16 * NI;
+    __shared__ __attribute__((aligned(16))) __bf16 Ah[TM * BF3_PITCH], Al[TM * BF3_PITCH];
+    __shared__ __attribute__((aligned(16))) __bf16 Bh[TN * BF3_PITCH], Bl[TN * BF3_PITCH];
+    __shared__ float s_red[4][TN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.z;
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const int nx = gridDim.x, ny8 = (gridDim.y / 8) * 8;
+        const int id = blockIdx.x + nx * blockIdx.y;
+        if (id < nx * ny8) {
+            const int xcd = id & 7, slot = id >> 3;
+            bx = slot % nx;
+            by = (slot / nx) * 8 + xcd;
         }
     }
+    const int m0 = by * TM, n0 = bx * TN;
+    if (p.gate_axis == 1) {
+        const int seg = p.tile_seg[by];
+        if (seg < 0) return;
+        if (p.active && !p.active[seg * p.active_ld + g]) return;
+    }
+    const float* Ag = p.A + (int64_t)g * p.a_gs;
+    const float* Bg = p.B + (int64_t)g * p.b_gs;
+    const int k_end = p.K;
+
+    f32x4 acc[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    Bf3Loader<TM> la;
+    Bf3Loader<TN> lb;
+    const bool full_mn = (m0 + TM <= p.M) && (n0 + TN <= p.N);
+    auto load_tiles = [&](int kk0) {
+        if (full_mn && kk0 + GEMM_BK <= k_end) {
+            la.template load<true>(Ag, p.lda, m0, p.M, kk0, k_end);
+            lb.template load<true>(Bg, p.ldb, n0, p.N, kk0, k_end);
+        } else {
+            la.template load<false>(Ag, p.lda, m0, p.M, kk0, k_end);
+            lb.template load<false>(Bg, p.ldb, n0, p.N, kk0, k_end);
+        }
+    };
+    load_tiles(0);
+    const int fr = lane & 15, fk = lane >> 4;              // fragment: row fr, k = 8*fk .. 8*fk+7
+    const int a_off = (wave * 16 + fr) * BF3_PITCH + 8 * fk;
+    const int b_off = fr * BF3_PITCH + 8 * fk;
+    for (int k0 = 0; k0 < k_end; k0 += GEMM_BK) {
+        la.store(Ah, Al);
+        lb.store(Bh, Bl);
+        __syncthreads();
+        if (k0 + GEMM_BK < k_end) load_tiles(k0 + GEMM_BK);
+        const bf16x8 ah = *(const bf16x8*)(Ah + a_off), al = *(const bf16x8*)(Al + a_off);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const bf16x8 bh = *(const bf16x8*)(Bh + b_off + i * 16 * BF3_PITCH);
+            const bf16x8 bl = *(const bf16x8*)(Bl + b_off + i * 16 * BF3_PITCH);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[i], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    gemm_epilogue<NI>(p, acc, g, 0, m0, n0, by, s_red);
 }
 
 // number of 16-column MFMA tiles per wave: 96-wide tiles when they cover N with less padding than 128-wide ones
@@ -291,3 +431,5 @@ static inline int gemm_ni(int N) {
     return N > 32 ? 4 : (N > 16 ? 2 : 1);
 }
 int launch_gemm(const GemmP& p, bool a_kc, bool b_kc, hipStream_t st);
+// split-bf16 variant: both operands k-contiguous, no split-K / k-gating
+int launch_gemm_bf3(const GemmP& p, hipStream_t st);

@@ -33,6 +33,27 @@ int launch_gemm(const GemmP& p_in, bool a_kc, bool b_kc, hipStream_t st) {
     return AREAD_OK;
 }
 
+int launch_gemm_bf3(const GemmP& p_in, hipStream_t st) {
+    GemmP p = p_in;
+    AR_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0 && p.G > 0, "gemm_bf3: empty problem");
+    AR_CHECK_ARG(p.lda % 4 == 0 && p.ldb % 4 == 0 && p.a_gs % 4 == 0 && p.b_gs % 4 == 0, "gemm_bf3: strides must be multiples of 4");
+    AR_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.B & 15) == 0, "gemm_bf3: operands must be 16-byte aligned");
+    AR_CHECK_ARG(p.gate_axis != 2, "gemm_bf3: k-gating is not supported");
+    AR_CHECK_ARG(p.gate_axis == 0 || p.tile_seg != nullptr, "gemm_bf3: gating needs tile_seg");
+    p.k_split = 1; p.k_chunk = p.K; p.c_ks = 0;
+    const int ni = gemm_ni(p.N);
+    dim3 grid(cdiv(p.N, 16 * ni), cdiv(p.M, 64), p.G);
+    switch (ni) {
+        case 8: hipLaunchKernelGGL((k_gemm_bf3<8>), grid, dim3(GEMM_THREADS), 0, st, p); break;
+        case 6: hipLaunchKernelGGL((k_gemm_bf3<6>), grid, dim3(GEMM_THREADS), 0, st, p); break;
+        case 4: hipLaunchKernelGGL((k_gemm_bf3<4>), grid, dim3(GEMM_THREADS), 0, st, p); break;
+        case 2: hipLaunchKernelGGL((k_gemm_bf3<2>), grid, dim3(GEMM_THREADS), 0, st, p); break;
+        default: hipLaunchKernelGGL((k_gemm_bf3<1>), grid, dim3(GEMM_THREADS), 0, st, p); break;
+    }
+    AR_LAUNCH_CHECK();
+    return AREAD_OK;
+}
+
 extern "C" int aread_gemm(const float* A, int64_t lda, int64_t a_gs, int a_kc, const float* B, int64_t ldb,
                           int64_t b_gs, int b_kc, float* C, int64_t ldc, int64_t c_gs, const float* bias,
                           int64_t bias_gs, int M, int N, int K, int G, int accumulate, void* stream) {
@@ -46,4 +67,18 @@ extern "C" int aread_gemm(const float* A, int64_t lda, int64_t a_gs, int a_kc, c
     p.k_split = 1; p.k_chunk = K;
     AR_CHECK_ARG(A && B && C, "aread_gemm: null pointer");
     return launch_gemm(p, a_kc != 0, b_kc != 0, (hipStream_t)stream);
+}
+
+extern "C" int aread_gemm_bf16x3(const float* A, int64_t lda, int64_t a_gs, const float* B, int64_t ldb, int64_t b_gs, float* C,
+                                 int64_t ldc, int64_t c_gs, const float* bias, int64_t bias_gs, int M, int N, int K, int G,
+                                 int accumulate, void* stream) {
+    GemmP p = {};
+    p.A = A; p.lda = lda; p.a_gs = a_gs;
+    p.B = B; p.ldb = ldb; p.b_gs = b_gs;
+    p.C = C; p.ldc = ldc; p.c_gs = c_gs;
+    p.bias = bias; p.bias_gs = bias_gs;
+    p.M = M; p.N = N; p.K = K; p.G = G;
+    p.accumulate = accumulate;
+    AR_CHECK_ARG(A && B && C, "aread_gemm_bf16x3: null pointer");
+    return launch_gemm_bf3(p, (hipStream_t)stream);
 }

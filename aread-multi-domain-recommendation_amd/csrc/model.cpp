@@ -61,6 +61,7 @@ extern "C" int aread_model_create(const aread_model_cfg* c, aread_model** out) {
     AR_CHECK_ARG(c->n_cross >= 0 && c->n_cross <= MAX_CROSS, "n_cross=%d not in [0,%d]", c->n_cross, MAX_CROSS);
     AR_CHECK_ARG(c->n_domain >= 1 && c->n_domain <= MAX_SEG, "n_domain=%d not in [1,%d]", c->n_domain, MAX_SEG);
     AR_CHECK_ARG(c->dropout >= 0.f && c->dropout < 1.f, "dropout=%f not in [0,1)", c->dropout);
+    AR_CHECK_ARG(c->precision == 0 || c->precision == 1, "precision=%d must be 0 (fp32) or 1 (split-bf16)", c->precision);
     for (int j = 0; j < c->n_expert_layers; ++j)
         AR_CHECK_ARG(c->expert_dims[j] > 0 && c->expert_dims[j] % 4 == 0 && c->expert_dims[j] <= 4096,
                      "expert_dims[%d]=%d must be a positive multiple of 4", j, c->expert_dims[j]);
@@ -209,6 +210,7 @@ static void layer_ws(const LayerL& L, int64_t rows, int64_t tiles, int n_seg, La
     w->bpart = take(o, tiles * L.ncols * 2);
     w->s12 = take(o, (int64_t)n_seg * L.ncols * 2);
     w->cpart = take(o, tiles * L.ncols);
+    w->wT = take(o, (int64_t)L.ncols * L.in_dim);
 }
 
 void ws_layout(const aread_model* m, int64_t B, int n_seg, WsLayout* w) {

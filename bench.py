@@ -24,6 +24,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured float4 copy)
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 runs at the fp32 vector peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 
 
 def parse():
@@ -38,13 +39,15 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=6)
     ap.add_argument("--dropout", type=float, default=0.2)
     ap.add_argument("--domain-dist", default="proportional", choices=["proportional", "uniform"])
+    ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3"],
+                    help="GEMM arithmetic of the expert/tower forward+dgrad: exact fp32 MFMA or split-bf16 (3 products)")
     ap.add_argument("--force-dp", action="store_true", help="use the multi-GPU code path even with one rank (testing)")
     return ap.parse_args()
 
 
-def build(spec, device, seed=123):
+def build(spec, device, seed=123, precision="f32"):
     from tests.util import build_model
-    model, P = build_model(spec, seed, device=device)
+    model, P = build_model(spec, seed, device=device, precision=precision)
     model.train()
     return model, P
 
@@ -79,7 +82,7 @@ def main():
     mrng = np.random.default_rng(2000)
     masks = [O.random_valid_mask(spec, mrng, 0.7) for _ in range(spec.n_domain)]
     log("building model + parameters")
-    model, P = build(spec, dev)
+    model, P = build(spec, dev, precision=args.precision)
     log("model ready")
     model.domain_mask = [[torch.tensor(m, dtype=torch.bool, device=dev) for m in mk] for mk in masks]
     masks_dev = aread_amd.pack_masks(masks, spec.n_domain, model.edge_num, dev)
@@ -190,14 +193,18 @@ def main():
     value = world * B * args.steps / dt
 
     # ---- roofline of the dominant kernel: the dense-L2 table sweep (read table, write dense gradient) ----
-    roofline = measure_gemm_kernel(model, bufs, L, B)           # dominant kernel by rocprof share (profiles/)
+    gemm = measure_gemm_kernel(model, bufs, L, B, args.precision)
     l2pass = measure_l2_kernel(model, bufs, L)
     gather = measure_gather_kernel(model, xs, bufs, L)
+    # `roofline` = the single most expensive kernel launch of the step (longest average duration, cf. profiles/)
+    roofline = max((gemm, l2pass), key=lambda r: r["avg_launch_us"])
 
     out = {
         "metric": "CTR samples/s fwd+bwd, AREAD 25-domain batch=8192", "value": round(value, 1), "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.precision == "f32" else "bf16x3 (split-bf16 fwd/dgrad GEMMs, fp32 accumulate) + f32",
+        "data": "synthetic",
         "config": {"workload": "AREAD HEI+HEMP-mask fwd+bagging BCE+L2+bwd, Amazon-like 25-domain, dims "
                                "[1368287,7,25,45,11,22356,10], E=32, 17 id columns, experts 4x(256,128,64), towers 3/6/12",
                    "batch_per_gpu": B, "global_batch": B * world, "domain_dist": args.domain_dist,
@@ -205,7 +212,8 @@ def main():
                    "dense_table_l2_in_timed_region": True, "launch": "hipGraph replay" if graph is not None else "eager, fork-join side streams",
                    "parallelism": f"dp{world}" + (": replicated table, all_gather(ids,dE)+all_reduce(dense grads) over RCCL"
                                                    if use_dp else "")},
-        "roofline": roofline, "l2_table_roofline": l2pass, "gather_roofline": gather, "loss": round(loss, 6),
+        "roofline": roofline, "gemm_roofline": gemm, "l2_table_roofline": l2pass, "gather_roofline": gather,
+        "loss": round(loss, 6),
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(O, spec, P, masks, batches, args)
@@ -239,7 +247,7 @@ def _pmc_traffic(kernel):
         return None
 
 
-def measure_gemm_kernel(model, bufs, L, B):
+def measure_gemm_kernel(model, bufs, L, B, precision):
     """Expert layer 1 forward: H1[rows,1024] = E[rows,288] . W1[1024,288]^T + b  (k_gemm<8,true,true>), the single most
     expensive kernel of the step.  Algorithmic FLOPs = 2 * 288 * 1024 per SAMPLE x B samples; the launch
     itself runs on the tile-padded row count."""
@@ -251,10 +259,20 @@ def measure_gemm_kernel(model, bufs, L, B):
     bias = model.dense.data[b_off:b_off + h1]
     out = torch.empty((rows, h1), device=W.device)
     A = bufs["e"]
+    alg = 2.0 * D * h1 * B
+    if precision == "bf16x3":
+        fn = lambda: L.check(L.lib().aread_gemm_bf16x3(L.ptr(A), D, 0, L.ptr(W), D, 0, L.ptr(out), h1, 0, L.ptr(bias), 0, rows, h1,
+                                                       D, 1, 0, L.stream()))
+        t = _time_kernel(fn)
+        ach = alg / t / 1e12
+        return {"kernel": "k_gemm_bf3<8> (expert layer 1 forward, split-bf16)", "bound": "mfma", "achieved": round(ach, 2),
+                "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4),
+                "issued_frac": round(3 * ach * rows / B / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "algorithmic_flops_per_launch": alg, "issued_flops_per_launch": 3 * 2.0 * D * h1 * rows,
+                "avg_launch_us": round(t * 1e6, 2), "mfma": "v_mfma_f32_16x16x32_bf16 x3 (hi*hi + hi*lo + lo*hi), f32 accumulate"}
     fn = lambda: L.check(L.lib().aread_gemm(L.ptr(A), D, 0, 1, L.ptr(W), D, 0, 1, L.ptr(out), h1, 0, L.ptr(bias), 0, rows, h1, D,
                                             1, 0, L.stream()))
     t = _time_kernel(fn)
-    alg = 2.0 * D * h1 * B
     ach = alg / t / 1e12
     return {"kernel": "k_gemm<8,true,true> (expert layer 1 forward)", "bound": "mfma", "achieved": round(ach, 2),
             "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4),

@@ -130,6 +130,14 @@ int aread_gemm(const float* A, int64_t lda, int64_t a_gs, int a_kc,
                float* C, int64_t ldc, int64_t c_gs, const float* bias, int64_t bias_gs,
                int M, int N, int K, int G, int accumulate, void* stream);
 
+/* The same product with both operands k-contiguous on the bf16 matrix cores, fp32 operands split on the fly
+ * into hi + lo bf16 (3 products hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16, fp32 accumulate):
+ * ~1e-6 relative error, 3/16 of the fp32-MFMA matrix-pipe time.  Used for the forward and dgrad GEMMs of the
+ * expert / tower layers when aread_model_cfg.precision == 1. */
+int aread_gemm_bf16x3(const float* A, int64_t lda, int64_t a_gs, const float* B, int64_t ldb, int64_t b_gs,
+                      float* C, int64_t ldc, int64_t c_gs, const float* bias, int64_t bias_gs,
+                      int M, int N, int K, int G, int accumulate, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Dense part of the model: linear term, cross network, MMoE bottom, masked HEI tower pyramid, heads,
  * bagging loss -- forward and backward.  Replaces AREAD.forward / hier_tower_mask_forward
@@ -151,6 +159,8 @@ typedef struct aread_model_cfg {
     int32_t n_cross, n_domain;
     float dropout;
     float l2_linear, l2_dnn, l2_cross;
+    int32_t precision;      /* 0: every GEMM on the exact fp32 MFMA (parity mode); 1: forward and dgrad GEMMs of the
+                               expert/tower layers on split-bf16 (3 products, ~4e-6 rms relative), wgrad stays fp32 */
 } aread_model_cfg;
 
 typedef struct aread_tensor_desc {

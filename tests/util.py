@@ -66,9 +66,10 @@ def check_grads(G, prefix, grads, rtol=2e-4, atol_scale=2e-5, skip=(), floor=2e-
 
 
 # ---- helpers for the HIP-side model (GPU tests, smoke, bench) ---------------------------------------
-def model_config(spec):
+def model_config(spec, precision="f32"):
     import types
     cfg = types.SimpleNamespace()
+    cfg.aread_precision = precision
     cfg.dataset_name = "synthetic"
     cfg.domain_size = {"synthetic": [100 + d for d in range(spec.n_domain)]}
     cfg.use_dcn, cfg.use_atten = True, bool(spec.with_dead_attention)
@@ -77,7 +78,7 @@ def model_config(spec):
     return cfg
 
 
-def build_model(spec, seed, device="cuda", dropout=None):
+def build_model(spec, seed, device="cuda", dropout=None, precision="f32"):
     """aread_amd.AREAD with the parameters of oracle.init_params(spec, seed) (strict state_dict load)."""
     import aread_amd
     mh = {"multi_hot_flag": list(spec.multi_hot_flag), "itemid_idx": spec.itemid_idx, "seq_maxlen": spec.seq_maxlen,
@@ -86,7 +87,7 @@ def build_model(spec, seed, device="cuda", dropout=None):
                             tuple(spec.expert_dims), tuple(tuple(t) for t in spec.tower_dims), spec.domain_idx,
                             n_cross_layers=spec.n_cross, dropout=spec.dropout if dropout is None else dropout,
                             device=device, l2_reg_embedding=spec.l2_embedding, l2_reg_linear=spec.l2_linear,
-                            l2_reg_dnn=spec.l2_dnn, l2_reg_cross=spec.l2_cross, config=model_config(spec))
+                            l2_reg_dnn=spec.l2_dnn, l2_reg_cross=spec.l2_cross, config=model_config(spec, precision))
     P = O.init_params(spec, seed)
     model.load_state_dict(P, strict=True)
     return model.to(device), P

@@ -40,6 +40,11 @@ def main():
         t = timeit(fn)
         fl = 2.0 * M * N * K * G
         print(f"{name:28s} {t:8.1f} us  {fl / t / 1e6:7.1f} TFLOP/s  ({fl / t / 1e6 / 157.3 * 100:4.1f}% of f32 MFMA peak)")
+        if akc and bkc:
+            f3 = lambda: L.check(L.lib().aread_gemm_bf16x3(L.ptr(A), lda, a_gs, L.ptr(B), ldb, b_gs, L.ptr(C), N, M * N, None, 0,
+                                                           M, N, K, G, 0, L.stream()))
+            t3 = timeit(f3)
+            print(f"{'   (split-bf16, 3 MFMA products)':28s} {t3:8.1f} us  {fl / t3 / 1e6:7.1f} TFLOP/s algorithmic")
         if akc and bkc and G == 1:
             a2, b2 = A.view(M, K), B.view(N, K)
             t2 = timeit(lambda: torch.mm(a2, b2.t()))
