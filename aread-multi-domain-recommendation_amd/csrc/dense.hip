@@ -1,6 +1,7 @@
 // dense.hip -- aread_forward / aread_backward: launch sequence of the dense path.
 // No allocation, no synchronisation, no host<->device copy: the whole sequence can be captured
 // into a hipGraph by the caller.
+#include <cstring>
 #include "dense_bwd_kernels.h"
 #include "gemm.h"
 
@@ -302,7 +303,7 @@ static int layer_bwd(Ctx& x, const LayerL& L, const LayerWs& lw, const float* in
     LAUNCH(k_act_bwd, dim3(x.n_tiles, cdiv(L.ncols, 64)), dim3(256), a);
     BnBwdApplyP b = {};
     b.d = d; b.H = ws + lw.H; b.mean = ws + lw.mean; b.rstd = ws + lw.rstd; b.gamma = x.params + L.gamma; b.bpart = ws + lw.bpart;
-    b.cpart = ws + lw.cpart; b.ncols = L.ncols; b.h = L.out_dim; b.level = level; b.r = x.r; b.mp = x.mp;
+    b.cpart = ws + lw.cpart; b.ncols = L.ncols; b.h = L.out_dim; b.level = level; b.train = x.c->train; b.r = x.r; b.mp = x.mp;
     LAUNCH(k_bn_bwd_apply, dim3(x.n_tiles, cdiv(L.ncols, 64)), dim3(256), b);
     AR_CHECK_ARG(x.bias.n < MAX_BN_LAYERS_DECL, "too many layers");
     BiasOne& bo = x.bias.d[x.bias.n++];
@@ -475,6 +476,115 @@ extern "C" int aread_join(const aread_model* m, void* stream) {
     hipEvent_t e = m->ev[m->n_ev - 1];
     AR_HIP(hipEventRecord(e, m->side));
     AR_HIP(hipStreamWaitEvent((hipStream_t)stream, e, 0));
+    return AREAD_OK;
+}
+
+// ================================================================================================
+// stand-alone MLP block (MultiLayerPerceptron, layer.py:203-229) on the same layer kernels
+// ================================================================================================
+// dst[r][0..cols) = r < B ? src[r][0..cols) : 0     (ld_dst = ld_src = cols unless given)
+__global__ __launch_bounds__(256) void k_pad_rows(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int cols, int64_t B,
+                                                  int64_t rows) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * cols) return;
+    const int64_t r = idx / cols;
+    const int c = (int)(idx - r * cols);
+    dst[r * ld_dst + c] = r < B ? src[r * ld_src + c] : 0.f;
+}
+
+static int make_mlp_ctx(const aread_model* m, const aread_mlp_call* c, void* stream, Ctx* x, aread_call* fake) {
+    AR_CHECK_ARG(m && m->is_mlp && c, "aread_mlp: not an MLP handle");
+    AR_CHECK_ARG(c->B > 0 && c->plan && c->params && c->ws && c->stats, "aread_mlp: null plan/params/stats/ws or B <= 0");
+    AR_CHECK_ARG(((uintptr_t)c->ws & 255) == 0 && ((uintptr_t)c->params & 15) == 0, "aread_mlp: alignment");
+    memset(fake, 0, sizeof(*fake));
+    fake->B = c->B; fake->n_seg = 1; fake->mode = 1; fake->train = c->train; fake->update_running = c->update_running;
+    fake->drop_seed = c->drop_seed; fake->plan = c->plan; fake->params = c->params; fake->stats = c->stats; fake->nbt = c->nbt;
+    fake->ws = c->ws;
+    x->m = m; x->c = fake; x->st = (hipStream_t)stream;
+    mlp_ws_layout(m, c->B, &x->w);
+    x->ws = (float*)c->ws;
+    x->rows = x->w.max_rows;
+    x->n_tiles = (int)x->w.n_tiles;
+    const PlanView pv = plan_view(c->plan, c->B, 1);
+    x->r.tile_seg = pv.tile_seg; x->r.tile_valid = pv.tile_valid; x->r.row_sample = pv.row_sample;
+    x->r.seg_count = pv.seg_count; x->r.seg_start = pv.seg_start; x->r.hdr = pv.hdr; x->r.n_tiles = x->n_tiles; x->r.n_seg = 1;
+    int32_t* ints = (int32_t*)(x->ws + x->w.kact);
+    x->mp.active = (const uint8_t*)(x->ws + x->w.active);
+    x->mp.kact = ints; x->mp.n0act = ints + MAX_SEG; x->mp.seg_dom = (int32_t*)(x->ws + x->w.seg_dom);
+    x->mp.masks = nullptr; x->mp.edge_count = 0; x->mp.mode = 1;
+    const bool drop = c->train && m->cfg.dropout > 0.f;
+    x->thr = drop ? drop_threshold(m->cfg.dropout) : 0u;
+    x->keep_scale = drop ? 1.0f / (1.0f - m->cfg.dropout) : 1.f;
+    x->params = c->params;
+    x->splitk.n = 0; x->bias.n = 0;
+    TRY0(model_streams_init(m));
+    x->side = m->side; x->ev_next = 0;
+    return AREAD_OK;
+}
+
+extern "C" int aread_mlp_forward(const aread_model* m, const aread_mlp_call* c, const float* xin, float* out, void* stream) {
+    Ctx x; aread_call fake;
+    TRY(make_mlp_ctx(m, c, stream, &x, &fake));
+    AR_CHECK_ARG(xin && out, "aread_mlp_forward: null x/out");
+    AR_CHECK_ARG(!(c->train && c->update_running) || c->nbt, "aread_mlp_forward: update_running needs nbt");
+    float* ws = x.ws;
+    const int in = m->mlp_in, nl = m->experts.n_layers, last = m->h_last;
+    LAUNCH(k_pad_rows, dim3(cdiv(x.rows * in, 256)), dim3(256), xin, (int64_t)in, ws + x.w.In[0], (int64_t)in, in, c->B, x.rows);
+    TRY(stack_fwd(x, m->experts, x.w.ex, ws + x.w.In[0], -1));
+    const float* act = ws + x.w.ex[nl - 1].Act;
+    if (m->mlp_out_layer) {
+        TRY(simple_gemm(x, act, last, true, x.params + m->out_w, last, true, ws + x.w.hc, 4, x.params + m->out_b, (int)x.rows, 1, last, 0, 1));
+        LAUNCH(k_pad_rows, dim3(cdiv(c->B, 256)), dim3(256), ws + x.w.hc, (int64_t)4, out, (int64_t)1, 1, c->B, c->B);
+    } else {
+        LAUNCH(k_pad_rows, dim3(cdiv(c->B * last, 256)), dim3(256), act, (int64_t)last, out, (int64_t)last, last, c->B, c->B);
+    }
+    if (c->train && c->update_running) {
+        BnRunAllP all = {};
+        int max_cols = 0;
+        for (int j = 0; j < nl; ++j) {
+            const LayerL& L = m->experts.L[j];
+            BnRunP& p = all.L[all.n_layers++];
+            p.mean = ws + x.w.ex[j].mean; p.var = ws + x.w.ex[j].var; p.rmean = c->stats + L.rmean; p.rvar = c->stats + L.rvar;
+            p.nbt = c->nbt + L.nbt0; p.ncols = L.ncols; p.h = L.out_dim; p.level = -1;
+            if (L.ncols > max_cols) max_cols = L.ncols;
+        }
+        all.r = x.r; all.mp = x.mp;
+        LAUNCH(k_bn_running, dim3(cdiv(max_cols, 256), all.n_layers), dim3(256), all);
+    }
+    return AREAD_OK;
+}
+
+extern "C" int aread_mlp_backward(const aread_model* m, const aread_mlp_call* c, const float* xin, const float* dout, float* grads,
+                                  float* dx, void* stream) {
+    Ctx x; aread_call fake;
+    TRY(make_mlp_ctx(m, c, stream, &x, &fake));
+    AR_CHECK_ARG(xin && dout && grads, "aread_mlp_backward: null x/dout/grads");
+    float* ws = x.ws;
+    const int in = m->mlp_in, nl = m->experts.n_layers, last = m->h_last;
+    AR_HIP(hipMemsetAsync(grads, 0, (size_t)m->n_params * sizeof(float), x.st));
+    float* dact_last = ws + x.w.ex[nl - 1].dAct;
+    if (m->mlp_out_layer) {
+        // dz [rows, 1] padded; dAct = dz * w_out ; dW_out = dz^T Act ; db_out = sum dz
+        LAUNCH(k_pad_rows, dim3(cdiv(x.rows, 256)), dim3(256), dout, (int64_t)1, ws + x.w.dz, (int64_t)4, 1, c->B, x.rows);
+        TRY(simple_gemm(x, ws + x.w.dz, 4, true, x.params + m->out_w, last, false, dact_last, last, nullptr, (int)x.rows, last, 1, 0, 1));
+        TRY(wgrad(x, ws + x.w.dz, 4, 0, ws + x.w.ex[nl - 1].Act, last, 0, 1, 1, last, grads + m->out_w, last, 0, nullptr, x.w.slab_head));
+        LAUNCH(k_colsum, dim3(x.n_tiles), dim3(256), ws + x.w.dz, (int64_t)4, 1, ws + x.w.misc_part, (int64_t)1024, x.r);
+        LAUNCH(k_reduce_tiles, dim3(1), dim3(256), ws + x.w.misc_part, (int64_t)1024, 1, grads + m->out_b, 1, (int64_t)0, 0, 1, x.r);
+    } else {
+        LAUNCH(k_pad_rows, dim3(cdiv(x.rows * last, 256)), dim3(256), dout, (int64_t)last, dact_last, (int64_t)last, last, c->B, x.rows);
+    }
+    for (int j = nl - 1; j >= 0; --j) {
+        const float* inp = j == 0 ? ws + x.w.In[0] : ws + x.w.ex[j - 1].Act;
+        float* d_in = j == 0 ? (dx ? ws + x.w.dIn[0] : nullptr) : ws + x.w.ex[j - 1].dAct;
+        TRY(layer_bwd(x, m->experts.L[j], x.w.ex[j], inp, d_in, 0, grads, -1, x.w.slab_ex[j]));
+    }
+    if (dx) LAUNCH(k_pad_rows, dim3(cdiv(c->B * in, 256)), dim3(256), ws + x.w.dIn[0], (int64_t)in, dx, (int64_t)in, in, c->B, c->B);
+    const hipStream_t main_st = x.st;
+    TRY(fork_side(x));
+    x.st = x.side;
+    TRY(flush_reductions(x));
+    x.st = main_st;
+    TRY(join_side(x));
     return AREAD_OK;
 }
 

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void k_act_bwd(const ActBwdP p) {
 struct BnBwdApplyP {
     float* d; const float* H; const float* mean; const float* rstd; const float* gamma; const float* bpart;
     float* cpart;                       // [n_tiles][ncols]
-    int ncols, h, level;
+    int ncols, h, level, train;         // train == 0: statistics are constants (running stats): dH = gamma*rstd*dyhat
     RowsP r; ModeP mp;
 };
 
@@ -303,7 +303,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const BnBwdApplyP p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             mu[i] = p.mean[so + i]; rs[i] = p.rstd[so + i]; ga[i] = p.gamma[c + i];
-            m1[i] = s_sum[(cq * 4 + i) * 2] * inv_n; m2[i] = s_sum[(cq * 4 + i) * 2 + 1] * inv_n;
+            m1[i] = p.train ? s_sum[(cq * 4 + i) * 2] * inv_n : 0.f;
+            m2[i] = p.train ? s_sum[(cq * 4 + i) * 2 + 1] * inv_n : 0.f;
         }
     }
     for (int rr = rg; rr < nvalid; rr += 16) {

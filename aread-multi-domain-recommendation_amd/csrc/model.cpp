@@ -313,3 +313,73 @@ extern "C" int64_t aread_debug_ws_offset(const aread_model* m, int64_t B, int n_
         return layer_field(w.tw[l][j], f);
     return -1;
 }
+
+// ------------------------------------------------------------------------------------------------
+// stand-alone MLP (MultiLayerPerceptron, layer.py:203-229)
+// ------------------------------------------------------------------------------------------------
+extern "C" int aread_mlp_create(const aread_mlp_cfg* c, aread_model** out) {
+    AR_CHECK_ARG(c && out, "aread_mlp_create: null argument");
+    AR_CHECK_ARG(c->in_dim > 0 && c->in_dim % 4 == 0, "in_dim=%d must be a positive multiple of 4", c->in_dim);
+    AR_CHECK_ARG(c->n_layers >= 1 && c->n_layers <= AREAD_MAX_LAYER, "n_layers=%d not in [1,%d]", c->n_layers, AREAD_MAX_LAYER);
+    AR_CHECK_ARG(c->dropout >= 0.f && c->dropout < 1.f, "dropout=%f not in [0,1)", c->dropout);
+    AR_CHECK_ARG(c->precision == 0 || c->precision == 1, "precision=%d", c->precision);
+    for (int j = 0; j < c->n_layers; ++j)
+        AR_CHECK_ARG(c->dims[j] > 0 && c->dims[j] % 4 == 0, "dims[%d]=%d must be a positive multiple of 4", j, c->dims[j]);
+    aread_model* m = new aread_model();
+    memset(&m->cfg, 0, sizeof(m->cfg));
+    m->cfg.n_expert = 1; m->cfg.n_expert_layers = c->n_layers; m->cfg.n_level = 0; m->cfg.n_domain = 1;
+    m->cfg.dropout = c->dropout; m->cfg.precision = c->precision; m->cfg.l2_dnn = 0.f;
+    for (int j = 0; j < c->n_layers; ++j) m->cfg.expert_dims[j] = c->dims[j];
+    m->is_mlp = true; m->mlp_in = c->in_dim; m->mlp_out_layer = c->output_layer;
+    m->D = c->in_dim; m->E = 0; m->n_heads = 0; m->h_last = c->dims[c->n_layers - 1]; m->head_ld = 0;
+    int64_t po = 0, so = 0;
+    int nbt = 0;
+    layout_stack(m, &m->experts, 1, c->in_dim, c->dims, c->n_layers, 0, true, c->in_dim, 0,
+                 [](int) { return std::string(""); }, &po, &so, &nbt);
+    for (auto& t : m->tensors) {                       // ".layers.N.x" -> "layers.N.x"
+        std::string n = t.name;
+        if (!n.empty() && n[0] == '.') n = n.substr(1);
+        snprintf(t.name, sizeof(t.name), "%s", n.c_str());
+    }
+    if (c->output_layer) {
+        const int last = m->h_last;
+        m->out_w = po; po += pad4(last);
+        m->out_b = po; po += 4;
+        const std::string p = "layers." + std::to_string(4 * c->n_layers);
+        add_tensor(m, p + ".weight", 0, m->out_w, 2, 1, last, 0.f);
+        add_tensor(m, p + ".bias", 0, m->out_b, 1, 1, 0, 0.f);
+    }
+    m->n_params = po; m->n_stats = so; m->n_bn = nbt;
+    m->edge_count = 0; m->gate_rows = 0; m->ld_ge = m->ld_gt = m->ld_h = 4;
+    *out = m;
+    return AREAD_OK;
+}
+
+void mlp_ws_layout(const aread_model* m, int64_t B, WsLayout* w) {
+    const int64_t rows = plan_max_rows(B, 1), tiles = rows / TILE_M;
+    int64_t o = 0;
+    memset(w, 0, sizeof(*w));
+    w->max_rows = rows; w->n_tiles = tiles;
+    w->In[0] = take(&o, rows * m->mlp_in);           // padded copy of x
+    w->dIn[0] = take(&o, rows * m->mlp_in);          // padded dx
+    w->hc = take(&o, rows * 4);                      // output layer: padded [rows, 1(+3)]
+    w->dz = take(&o, rows * 4);
+    for (int j = 0; j < m->experts.n_layers; ++j) {
+        layer_ws(m->experts.L[j], rows, tiles, 1, &w->ex[j], &o);
+        const LayerL& L = m->experts.L[j];
+        w->slab_ex[j] = take(&o, (int64_t)L.out_dim * L.in_dim * wgrad_ksplit(rows, 1, L.out_dim, L.in_dim).k_split);
+    }
+    w->slab_head = take(&o, (int64_t)m->h_last * wgrad_ksplit(rows, 1, 1, m->h_last).k_split + 64);
+    w->active = take(&o, (int64_t)AREAD_MAX_LEVEL * MAX_SEG * MAX_TOWER / 4);
+    w->kact = take(&o, 2 * MAX_SEG);
+    w->seg_dom = take(&o, MAX_SEG);
+    w->misc_part = take(&o, tiles * 1024);
+    w->total = o;
+}
+
+extern "C" int64_t aread_mlp_workspace_bytes(const aread_model* m, int64_t B) {
+    if (!m || !m->is_mlp || B <= 0) return -1;
+    WsLayout w;
+    mlp_ws_layout(m, B, &w);
+    return w.total * 4;
+}

@@ -48,6 +48,10 @@ struct aread_model {
     int ld_ge, ld_gt, ld_h;                  // padded leading dims: MMoE gate logits, tower gate logits, heads
     std::vector<aread_tensor_desc> tensors;
     // side stream + event pool for fork-join concurrency inside one call (created on first use, per device)
+    // stand-alone MLP handle (aread_mlp_create): experts stack with G = 1, optional Linear(last, 1)
+    bool is_mlp = false;
+    int mlp_in = 0, mlp_out_layer = 0;
+    int64_t out_w = 0, out_b = 0;
     mutable hipStream_t side = nullptr;
     mutable hipEvent_t ev[64] = {};
     mutable int n_ev = 0;
@@ -68,6 +72,7 @@ struct WsLayout {                            // float offsets into the workspace
 };
 
 void ws_layout(const aread_model* m, int64_t B, int n_seg, WsLayout* w);
+void mlp_ws_layout(const aread_model* m, int64_t B, WsLayout* w);
 
 // split-K geometry of a wgrad GEMM (K = padded batch rows): enough slices to fill the chip
 struct KSplit { int k_split, k_chunk; };

@@ -216,6 +216,35 @@ int aread_forward(const aread_model* m, const aread_call* call_host, const float
  * de_out: [plan.max_rows][D], overwritten with the gradient w.r.t. e_in. */
 int aread_backward(const aread_model* m, const aread_call* call_host, const float* e_in, const float* dprobs,
                    float* grads, float* de_out, void* stream);
+/* ---------------------------------------------------------------------------------------------
+ * Stand-alone MLP block.  Replaces MultiLayerPerceptron (model/layer.py:203-229):
+ *   [Linear -> BatchNorm1d -> ReLU -> Dropout] x n_layers (+ Linear(last, 1) when output_layer != 0),
+ *   BatchNorm skipped for a one-row batch (layer.py:226).  One BN segment (the whole batch).
+ * The handle is an aread_model whose tensor table uses the keys of that module's state_dict
+ * ("layers.0.weight", "layers.1.running_mean", ...); params / stats / nbt / ws follow the same conventions.
+ * plan: aread_plan_build(NULL, B, 0, -1, 1, ...).  x: [B, in_dim], out: [B, dims[last]] or [B, 1].
+ * ------------------------------------------------------------------------------------------- */
+typedef struct aread_mlp_cfg {
+    int32_t in_dim, n_layers, dims[AREAD_MAX_LAYER], output_layer, precision;
+    float dropout;
+} aread_mlp_cfg;
+int aread_mlp_create(const aread_mlp_cfg* cfg_host, aread_model** out_host);
+int64_t aread_mlp_workspace_bytes(const aread_model* m, int64_t B);
+typedef struct aread_mlp_call {
+    int64_t B;
+    int32_t train, update_running;
+    uint32_t drop_seed;
+    const int32_t* plan;
+    const float* params;
+    float* stats;
+    int64_t* nbt;
+    void* ws;
+} aread_mlp_call;
+int aread_mlp_forward(const aread_model* m, const aread_mlp_call* call_host, const float* x, float* out, void* stream);
+/* grads: flat like params, overwritten; dx: [B, in_dim] or NULL. */
+int aread_mlp_backward(const aread_model* m, const aread_mlp_call* call_host, const float* x, const float* dout,
+                       float* grads, float* dx, void* stream);
+
 /* Makes `stream` wait for the model's internal side stream (see aread_call.async_tail). */
 int aread_join(const aread_model* m, void* stream);
 /* Dense L2 terms: loss_out[0] (+)= sum_i coef[i]*w[i]^2, grads[i] += 2*coef[i]*w[i] (grads may be NULL).

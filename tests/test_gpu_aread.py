@@ -254,3 +254,63 @@ def test_dp_path_single_rank_matches_fused_step():
         dist.destroy_process_group()
     assert res[0][0] == res[1][0]
     assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+
+
+@pytest.mark.parametrize("B", [1, 100, 700])
+@pytest.mark.parametrize("output_layer", [False, True])
+def test_multilayer_perceptron_vs_torch(B, output_layer):
+    """Drop-in MultiLayerPerceptron (layer.py:203-229) against the same block built from torch.nn on the CPU (fp32)."""
+    import aread_amd
+    torch.manual_seed(3)
+    dims, in_dim = (48, 24, 12), 40
+    ref = torch.nn.ModuleList()
+    d = in_dim
+    for h in dims:
+        ref += [torch.nn.Linear(d, h), torch.nn.BatchNorm1d(h), torch.nn.ReLU(), torch.nn.Dropout(0.0)]
+        d = h
+    if output_layer:
+        ref.append(torch.nn.Linear(d, 1))
+    for m in ref:
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.weight.data.uniform_(0.5, 1.5); m.bias.data.uniform_(-0.3, 0.3)
+            m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5)
+    sd = {f"layers.{k}": v for k, v in ref.state_dict().items()}
+    mlp = aread_amd.MultiLayerPerceptron(in_dim, dims, 0.0, output_layer=output_layer)
+    mlp.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+    mlp = mlp.cuda()
+    assert set(mlp.state_dict().keys()) == set(sd.keys())
+
+    def ref_fwd(x):
+        for m in ref:
+            if isinstance(m, torch.nn.BatchNorm1d) and x.shape[0] == 1:
+                continue
+            x = m(x)
+        return x
+
+    for train in (True, False):
+        ref.train(train); mlp.train(train)
+        x = torch.randn(B, in_dim)
+        xr = x.clone().requires_grad_(True)
+        xg = x.clone().cuda().requires_grad_(True)
+        yr = ref_fwd(xr)
+        yg = mlp(xg)
+        assert tuple(yg.shape) == tuple(yr.shape)
+        np.testing.assert_allclose(yg.detach().cpu().numpy(), yr.detach().numpy(), rtol=2e-4, atol=2e-5)
+        w = torch.randn_like(yr)
+        ref.zero_grad(); mlp.zero_grad()
+        (yr * w).sum().backward()
+        (yg * w.cuda()).sum().backward()
+        np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=2e-3, atol=2e-5)
+        got = {n: v for n, v in zip([t[0] for t in mlp._tensors if t[1] == 0],
+                                    [mlp.dense.grad[t[2]:t[2] + int(np.prod(t[3]))].view(t[3]).cpu().numpy()
+                                     for t in mlp._tensors if t[1] == 0])}
+        for k, p in ref.named_parameters():
+            g = p.grad.numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)   # B == 1: BN skipped
+            idx = int(k.split(".")[0])
+            pre_bn_bias = k.endswith("bias") and idx % 4 == 0 and idx < 4 * len(dims) and train and B > 1
+            atol = 1e-3 if pre_bn_bias else max(2e-5, 3e-5 * np.abs(g).max())     # d(bias before BN) is exactly 0: fp noise
+            np.testing.assert_allclose(got[f"layers.{k}"], g, rtol=2e-3, atol=atol, err_msg=k)
+    sd2 = mlp.state_dict()
+    for k, v in ref.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            np.testing.assert_allclose(sd2[f"layers.{k}"].cpu().numpy(), v.numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
