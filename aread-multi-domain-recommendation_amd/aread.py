@@ -477,7 +477,7 @@ class AREAD(HempMixin, nn.Module):
         return self._streams[key]
 
     def step_local(self, x, y, bufs, masks_dev=None, domain_i=None, seg_weight=None, with_reg=True,
-                   with_dense_l2=True, want_gates=False, presort=True):
+                   with_dense_l2=True, want_gates=False, presort=True, plan=None):
         """Rank-local part of the step: row plan, gather, dense forward + bagging BCE + backward on the current
         stream; concurrently on a side stream (fork-join, capturable): the table L2 pass
         (bufs['gtable'] = 2*l2*W, bufs['reg'] = l2 terms) and, with presort, the index sort of the embedding
@@ -488,7 +488,8 @@ class AREAD(HempMixin, nn.Module):
         table = self.embedding.embedding_dict.weight
         if masks_dev is None:
             masks_dev = self._masks_dev(self.domain_mask, x.device)
-        plan = RowPlan(x, self.domain_idx if n_seg > 1 else -1, n_seg)
+        if plan is None:
+            plan = RowPlan(x, self.domain_idx if n_seg > 1 else -1, n_seg)
         main, side = torch.cuda.current_stream(), self._side_stream(x.device)
         part = self._l2_partials(x.device)
         self.embedding._ws_for(x)                      # allocate on the main stream's pool before forking

@@ -99,11 +99,13 @@ def main():
         dp = DataParallelStep(model, B)
         bufs = dp.bufs
 
-        def step():                                   # rank-local part (graph-captured)
-            dp_state["st"] = dp.local(xs, ys, masks_dev)
+        args.no_graph = True                          # the multi-GPU step is eager: collectives interleave with compute
 
-        def after():                                  # collectives + global scatter (eager)
-            dp.exchange_and_scatter(xs, dp_state["st"])
+        def step():
+            dp.step(xs, ys, masks_dev)
+
+        def after():
+            pass
     else:
         bufs = model.make_step_buffers(B, multi_domain=True, device=dev)
 

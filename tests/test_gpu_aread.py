@@ -239,12 +239,12 @@ def test_dp_path_single_rank_matches_fused_step():
     os_env.setdefault("MASTER_ADDR", "127.0.0.1"); os_env.setdefault("MASTER_PORT", "29577")
     dist.init_process_group("nccl", rank=0, world_size=1)
     try:
-        for use_dp in (False, True):
+        for use_dp in (False, True, "overlap"):
             model, _ = U.build_model(spec, seed)
             model.train()
             md = aread_amd.pack_masks(masks, spec.n_domain, model.edge_num, "cuda")
             if use_dp:
-                dp = DataParallelStep(model, x.shape[0])
+                dp = DataParallelStep(model, x.shape[0], force_overlap=(use_dp == "overlap"))
                 loss = dp.step(x, y, md); bufs = dp.bufs
             else:
                 bufs = model.make_step_buffers(x.shape[0])
@@ -252,8 +252,9 @@ def test_dp_path_single_rank_matches_fused_step():
             res.append((float(loss), bufs["gdense"].clone(), bufs["gtable"].clone()))
     finally:
         dist.destroy_process_group()
-    assert res[0][0] == res[1][0]
-    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    for r in res[1:]:
+        assert res[0][0] == r[0]
+        assert torch.equal(res[0][1], r[1]) and torch.equal(res[0][2], r[2])
 
 
 @pytest.mark.parametrize("B", [1, 100, 700])
