@@ -88,9 +88,13 @@ class _CallState:
 
 
 class _AreadFn(torch.autograd.Function):
+    """autograd node of one forward call.  `table` and `anchor` (the first dense parameter) only tie the node into
+    the graph; the dense gradients are written by the library into one flat buffer and handed to the per-tensor
+    parameters as views (AREAD._accumulate_dense), with grad=None where the reference's autograd leaves None."""
+
     @staticmethod
-    def forward(ctx, table, dense, model, x, st):
-        ctx.model, ctx.st = model, st
+    def forward(ctx, table, anchor, model, x, st, present):
+        ctx.model, ctx.st, ctx.present = model, st, present
         ctx.table_shape = tuple(table.shape)
         return st.probs
 
@@ -102,36 +106,37 @@ class _AreadFn(torch.autograd.Function):
         de = torch.empty_like(st.e)
         L.check(L.lib().aread_backward(model._handle, C.byref(st.call), L.ptr(st.e), L.ptr(dprobs), L.ptr(grads),
                                        L.ptr(de), L.stream()))
+        model._accumulate_dense(grads, ctx.present, take=True)
         gtab = torch.zeros(ctx.table_shape, dtype=torch.float32, device=de.device)
         model.embedding.scatter_grad(st.x, de, gtab, st.plan.sample_row)
-        return gtab, grads, None, None, None
+        return gtab, None, None, None, None, None
 
 
 class _RegFn(torch.autograd.Function):
     """get_regularization_loss (layer.py:96-112) as one streaming pass per direction."""
 
     @staticmethod
-    def forward(ctx, table, dense, model):
+    def forward(ctx, table, anchor, model):
         ctx.model = model
-        ctx.save_for_backward(table, dense)
+        ctx.save_for_backward(table)
         out = torch.zeros(257, dtype=torch.float32, device=table.device)
         lib = L.lib()
         part = model._l2_partials(table.device)
         L.check(lib.aread_l2_table(L.ptr(table), table.numel(), model.l2_reg_embedding, 1.0, None, L.ptr(part), L.stream()))
         L.check(lib.aread_l2_finish(L.ptr(part), part.numel(), model.l2_reg_embedding, L.ptr(out), 0, L.stream()))
-        L.check(lib.aread_l2_dense(L.ptr(dense), L.ptr(model._l2_coef(table.device)), dense.numel(), None, L.ptr(out), 1,
-                                   L.stream()))
+        L.check(lib.aread_l2_dense(L.ptr(model.dense), L.ptr(model._l2_coef(table.device)), model.dense.numel(), None,
+                                   L.ptr(out), 1, L.stream()))
         return out[:1].clone()
 
     @staticmethod
     def backward(ctx, gout):
-        table, dense = ctx.saved_tensors
+        (table,) = ctx.saved_tensors
         model = ctx.model
         g = float(gout.reshape(-1)[0])      # scalar scale of the regulariser in the caller's loss
         gtab = torch.empty_like(table)
         L.check(L.lib().aread_l2_table(L.ptr(table), table.numel(), model.l2_reg_embedding, g, L.ptr(gtab), None, L.stream()))
-        gd = 2.0 * g * model._l2_coef(table.device) * dense.detach()
-        return gtab, gd, None
+        model._accumulate_dense(2.0 * g * model._l2_coef(table.device) * model.dense, model._reg_present, take=True)
+        return gtab, None, None
 
 
 class AREAD(HempMixin, nn.Module):
@@ -213,7 +218,13 @@ class AREAD(HempMixin, nn.Module):
             L.check(lib.aread_model_tensor(h, i, C.byref(d)))
             shape = tuple(int(d.shape[k]) for k in range(d.ndim))
             self._tensors.append((d.name.decode(), int(d.kind), int(d.offset), shape, float(d.l2)))
-        self.dense = nn.Parameter(torch.zeros(lib.aread_model_param_floats(h)))
+        # storage: ONE flat fp32 buffer read by the kernels; every reference tensor is a trainable nn.Parameter whose
+        # storage is a slice of it (so optimizers see the reference's per-tensor parameters and grad=None semantics)
+        self.register_buffer("dense", torch.zeros(lib.aread_model_param_floats(h)))
+        self._ptensors = [t for t in self._tensors if t[1] == 0]
+        self.dense_params = nn.ParameterList([nn.Parameter(self._view_of(self.dense, t)) for t in self._ptensors])
+        self._gflat = None
+        self._reg_present = [t[4] > 0 for t in self._ptensors]
         self.register_buffer("bn_stats", torch.zeros(lib.aread_model_stat_floats(h)))
         self.register_buffer("bn_nbt", torch.zeros(lib.aread_model_n_bn(h), dtype=torch.int64))
         # parameters that never influence the output (kept for checkpoint compatibility only)
@@ -244,9 +255,74 @@ class AREAD(HempMixin, nn.Module):
             pass
 
     # ---- parameters -----------------------------------------------------------------------------
+    @staticmethod
+    def _view_of(flat, t):
+        n = int(np.prod(t[3])) if t[3] else 1
+        return flat[t[2]:t[2] + n].view(t[3])
+
+    def _apply(self, fn, *args, **kwargs):
+        """Module.to()/cuda()/cpu(): move the flat buffer, then re-point every parameter at its slice."""
+        super()._apply(fn, *args, **kwargs)
+        for p, t in zip(self.dense_params, self._ptensors):
+            p.data = self._view_of(self.dense, t)
+            p.grad = None
+        self._gflat = None
+        return self
+
+    def named_dense_parameters(self):
+        """(reference state_dict key, nn.Parameter) for every dense tensor."""
+        return [(t[0], p) for t, p in zip(self._ptensors, self.dense_params)]
+
+    def _accumulate_dense(self, flat, present, take=False):
+        """Add a flat gradient contribution.  Tensors marked present get `.grad` (a view of the flat gradient buffer);
+        the others keep grad=None exactly as the reference's autograd leaves them (Adam then skips them)."""
+        fresh = all(p.grad is None for p in self.dense_params)
+        if fresh:
+            if take:
+                self._gflat = flat
+            else:
+                if self._gflat is None or self._gflat.device != flat.device:
+                    self._gflat = torch.empty_like(flat)
+                self._gflat.copy_(flat)
+        else:
+            self._gflat.add_(flat)
+        for p, t, pres in zip(self.dense_params, self._ptensors, present):
+            if pres and p.grad is None:
+                p.grad = self._view_of(self._gflat, t)
+
+    def _presence(self, mode_id, masks):
+        """Which dense tensors are on a gradient path of a forward call (what the reference's autograd would reach)."""
+        if mode_id == 1:
+            act = [[True] * n for n in self.n_tower]
+        else:
+            act = [[False] * n for n in self.n_tower]
+            for mk in masks:
+                if mk is None:
+                    continue
+                for l in range(self.n_level):
+                    a = np.asarray(mk[l].cpu() if isinstance(mk[l], torch.Tensor) else mk[l]).any(axis=0)
+                    for t in range(self.n_tower[l]):
+                        act[l][t] = act[l][t] or bool(a[t])
+        out = []
+        for name, *_ in self._ptensors:
+            k = name.split(".")
+            if k[0] == "mmoe_gates":
+                out.append(act[0][int(k[1])])
+            elif k[0] == "group_embedding":
+                out.append(mode_id == 0)
+            elif k[0] == "towers":
+                out.append(act[int(k[1])][int(k[2])])
+            elif k[0] == "tower_gates":
+                out.append(act[int(k[1]) + 1][int(k[2])])
+            elif k[0] == "towers_linear":
+                out.append(act[-1][int(k[1])])
+            else:
+                out.append(True)             # linear, cn, mmoe_experts
+        return out
+
     def named_views(self):
         """(reference key, tensor view) for every tensor that lives in dense / bn_stats / bn_nbt."""
-        bufs = {0: self.dense.data, 1: self.bn_stats, 2: self.bn_nbt}
+        bufs = {0: self.dense, 1: self.bn_stats, 2: self.bn_nbt}
         for name, kind, off, shape, _ in self._tensors:
             n = int(np.prod(shape)) if shape else 1
             yield name, bufs[kind][off:off + n].view(shape)
@@ -276,7 +352,7 @@ class AREAD(HempMixin, nn.Module):
     def _sd_hook(self, sd, prefix, local_metadata):
         out = OrderedDict()
         for k, v in sd.items():
-            if k in (prefix + "dense", prefix + "bn_stats", prefix + "bn_nbt"):
+            if k in (prefix + "dense", prefix + "bn_stats", prefix + "bn_nbt") or k.startswith(prefix + "dense_params."):
                 continue
             out[k] = v
         bufs = {0: sd[prefix + "dense"], 1: sd[prefix + "bn_stats"], 2: sd[prefix + "bn_nbt"]}
@@ -304,6 +380,8 @@ class AREAD(HempMixin, nn.Module):
             elif strict:
                 missing.append(k)
         sd[prefix + "dense"], sd[prefix + "bn_stats"], sd[prefix + "bn_nbt"] = bufs[0], bufs[1], bufs[2]
+        for i, t in enumerate(self._ptensors):
+            sd[prefix + f"dense_params.{i}"] = self._view_of(bufs[0], t)
 
     def _l2_coef(self, device):
         key = str(device)
@@ -320,7 +398,7 @@ class AREAD(HempMixin, nn.Module):
         return self._part[key]
 
     def get_regularization_loss(self, device=None):
-        return _RegFn.apply(self.embedding.embedding_dict.weight, self.dense, self)
+        return _RegFn.apply(self.embedding.embedding_dict.weight, self.dense_params[0], self)
 
     # ---- one call ---------------------------------------------------------------------------------
     def _masks_dev(self, masks, device):
@@ -373,6 +451,8 @@ class AREAD(HempMixin, nn.Module):
         for l in range(1, self.n_level):
             for t in range(self.n_tower[l]):
                 v = gate_row[off:off + self.n_tower[l - 1]].clone()
+                if self.device is not None:
+                    v = v.to(self.device)          # the HEMP host logic runs where the masks live
                 off += self.n_tower[l - 1]
                 if tmp_memory_gate_value:
                     self.tmp_tower_gate_values[l][t] = v
@@ -388,7 +468,8 @@ class AREAD(HempMixin, nn.Module):
         table = self.embedding.embedding_dict.weight
         if mode == "wo_mask":
             st, gate = self._run(x, 1, 1, domain_i, None, want_gates and domain_i is not None)
-            probs = _AreadFn.apply(table, self.dense, self, x, st) if torch.is_grad_enabled() else st.probs
+            probs = (_AreadFn.apply(table, self.dense_params[0], self, x, st, self._presence(1, None))
+                     if torch.is_grad_enabled() else st.probs)
             if want_gates and domain_i is not None:
                 self._record_gates(gate[0], domain_i, memory_gate_value, False)
             return probs.mean(dim=0).unsqueeze(-1)
@@ -407,7 +488,8 @@ class AREAD(HempMixin, nn.Module):
             if active.size == 0:
                 raise RuntimeError("mask has no active last-level tower (aread.py:312-322)")
             st, gate = self._run(x, 0, 1, d, self._masks_dev(masks, x.device), want_gates)
-            probs = _AreadFn.apply(table, self.dense, self, x, st) if torch.is_grad_enabled() else st.probs
+            probs = (_AreadFn.apply(table, self.dense_params[0], self, x, st, self._presence(0, [mask]))
+                     if torch.is_grad_enabled() else st.probs)
             if want_gates:
                 self._record_gates(gate[0], d, memory_gate_value, tmp_memory_gate_value)
             y_stack = probs[torch.from_numpy(active).to(x.device)]
@@ -416,7 +498,8 @@ class AREAD(HempMixin, nn.Module):
             if any(m is None for m in self.domain_mask):
                 raise ValueError("with_mask needs a mask for every domain")
             st, _ = self._run(x, 0, self.n_domain, None, self._masks_dev(self.domain_mask, x.device), False)
-            probs = _AreadFn.apply(table, self.dense, self, x, st) if torch.is_grad_enabled() else st.probs
+            probs = (_AreadFn.apply(table, self.dense_params[0], self, x, st, self._presence(0, self.domain_mask))
+                     if torch.is_grad_enabled() else st.probs)
             kact = torch.tensor([float(np.asarray(m[self.n_level - 1].cpu() if isinstance(m[0], torch.Tensor)
                                                   else m[self.n_level - 1]).any(axis=0).sum())
                                  for m in self.domain_mask], device=x.device)
@@ -465,7 +548,7 @@ class AREAD(HempMixin, nn.Module):
             loss=torch.zeros(1 + n_seg, dtype=torch.float32, device=device),
             reg=torch.zeros(257, dtype=torch.float32, device=device),
             total=torch.zeros(1, dtype=torch.float32, device=device),
-            gdense=torch.zeros_like(self.dense.data),
+            gdense=torch.zeros_like(self.dense),
             gtable=torch.empty_like(self.embedding.embedding_dict.weight.data),
         )
         return bufs
@@ -542,6 +625,10 @@ class AREAD(HempMixin, nn.Module):
         self.step_finish(bufs)
         torch.add(bufs["loss"][:1], bufs["reg"][:1], out=bufs["total"])
         if set_grads:
-            self.dense.grad = bufs["gdense"]
+            for p in self.dense_params:
+                p.grad = None
+            present = [a or b for a, b in zip(self._presence(0, self.domain_mask), self._reg_present)] if with_reg \
+                else self._presence(0, self.domain_mask)
+            self._accumulate_dense(bufs["gdense"], present, take=True)
             self.embedding.embedding_dict.weight.grad = bufs["gtable"]
         return bufs["total"]

@@ -305,6 +305,16 @@ def gen_hemp(path):
     print(f"wrote {path}: {len(out)} arrays")
 
 
+def gen_harness(path):
+    """One epoch of the training harness (aread_amd/harness.py) driving the REFERENCE model on the CPU."""
+    from tests.util import run_harness
+    spec = spec_full()
+    model, _ = build_reference(spec, 123)
+    out = run_harness(model, spec, torch.device("cpu"))
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {len(out['trace_vals'])} trace points, valid auc/logloss/mean_auc/mean_loss = {out['valid']}")
+
+
 if __name__ == "__main__":
     torch.manual_seed(2000)
     np.random.seed(2000)
@@ -313,3 +323,4 @@ if __name__ == "__main__":
     gen_model(os.path.join(HERE, "aread_full.npz"), spec_full(), 123, "full widths")
     gen_model(os.path.join(HERE, "aread_tiny.npz"), spec_tiny(), 321, "tiny/odd widths")
     gen_hemp(os.path.join(HERE, "hemp.npz"))
+    gen_harness(os.path.join(HERE, "harness.npz"))

@@ -95,13 +95,16 @@ def build_model(spec, seed, device="cuda", dropout=None, precision="f32"):
 
 def dense_grads(model, flat=None):
     """name -> numpy gradient for every tensor that lives in the flat dense parameter."""
-    g = (model.dense.grad if flat is None else flat).detach().cpu().numpy()
-    out = {}
-    for name, kind, off, shape, _ in model._tensors:
-        if kind == 0:
-            n = int(np.prod(shape)) if shape else 1
-            out[name] = g[off:off + n].reshape(shape)
-    return out
+    if flat is not None:
+        g = flat.detach().cpu().numpy()
+        out = {}
+        for name, kind, off, shape, _ in model._tensors:
+            if kind == 0:
+                n = int(np.prod(shape)) if shape else 1
+                out[name] = g[off:off + n].reshape(shape)
+        return out
+    return {name: (p.grad.detach().cpu().numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32))
+            for name, p in model.named_dense_parameters()}
 
 
 # ---- HEMP host-logic sequence: driven identically on the reference (golden generation) and on aread_amd ----
@@ -168,4 +171,49 @@ def hemp_sequence(model, spec, seed=7):
         for d in range(spec.n_domain):
             out[f"select/{d}"] = pk(model.domain_mask[d])
         out["active_ratio"] = np.array([model.count_current_active_ratio()])
+    return out
+
+
+
+# ---- harness run: driven identically on the reference (golden generation, CPU) and on aread_amd (GPU) -----------
+def harness_config():
+    import types
+    c = types.SimpleNamespace()
+    c.bs, c.lr, c.wd, c.update_lr = 64, 1e-3, 1e-8, 1e-2
+    c.warm_up_interval, c.regroup_interval = 0.25, 0.5          # -> 4 warm-up steps, regroup every 8 steps
+    c.regroup_update_step, c.regroup_eval_step = 2, 2
+    c.candidate_mask_num, c.random_modify_sigma, c.init_active_percent = 2.5, 0.2, 0.7
+    c.early_stop = 2
+    return c
+
+
+def harness_data(spec, seed=11):
+    rng = np.random.default_rng(seed)
+    def make(n):
+        x = np.stack([rng.integers(0, d, n) for d in spec.field_dims]
+                     + [rng.integers(0, spec.field_dims[0] + 1, n) for _ in range(spec.n_mh_slots)], axis=1).astype(np.int32)
+        w = rng.standard_normal(spec.f_in)
+        y = ((x * w).sum(1) % 7 < 3).astype(np.int16)             # a learnable-ish pattern
+        return x, y
+    return make(1000), make(300)
+
+
+def run_harness(model, spec, device, seed=5):
+    """One epoch of Trainer.main on the tiny dataset; returns the trace + final masks + validation result."""
+    import contextlib, io
+    import torch
+    from aread_amd.harness import DomainStreams, Trainer
+    (xt, yt), (xv, yv) = harness_data(spec)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    cfg = harness_config()
+    tr = DomainStreams(torch.from_numpy(xt), torch.from_numpy(yt), spec.n_domain, spec.domain_idx, cfg.bs, device)
+    va = DomainStreams(torch.from_numpy(xv), torch.from_numpy(yv), spec.n_domain, spec.domain_idx, cfg.bs, device)
+    t = Trainer(model, cfg, tr, va, device=device, log=lambda *a: None)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model.reset_for_mask_update()
+        res = t.main(epochs=1)
+    out = {"trace_tags": np.array([k for k, _ in t.trace]), "trace_vals": np.array([v for _, v in t.trace], dtype=np.float64)}
+    out["masks"] = np.stack([O.pack_mask(spec, m) for m in model.domain_mask])
+    out["valid"] = np.array([res[0]["total_auc"], res[0]["total_loss"], res[0]["mean_auc"], res[0]["mean_loss"]])
     return out
