@@ -315,3 +315,63 @@ def test_multilayer_perceptron_vs_torch(B, output_layer):
     for k, v in ref.state_dict().items():
         if "running" in k or "num_batches" in k:
             np.testing.assert_allclose(sd2[f"layers.{k}"].cpu().numpy(), v.numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
+
+
+@pytest.mark.parametrize("domain_dist", ["proportional", "uniform"])
+def test_baseline_size_step_vs_oracle_both_precisions(domain_dist):
+    """BASELINE config (Amazon-like dims, 1.39 M-row table, 25 domains, B=8192): fused step vs the CPU oracle.
+    Logits inside the north star's tolerance |d| <= 1e-4 * max(|ref|, 1) in the exact-fp32 mode AND in the
+    split-bf16 mode bench.py runs; loss to 5e-5; gradients on the uniform-domain batch.
+
+    With domains drawn proportionally to config.py:60-61, a B=8192 batch contains domains of 1-3 rows.  BatchNorm
+    over 2-3 rows is ill-conditioned in ANY fp32 implementation (x_hat = +-1 for two rows; rstd up to 1/sqrt(eps)
+    per layer): the fp32 oracle itself differs from an fp64 oracle by 100 % on those gradients
+    (tools/debug_small_segments.py).  Logits are therefore asserted on domains with >= 8 rows (> 99 % of the
+    samples) and gradients on the uniform batch."""
+    import aread_amd
+    from tools import synth
+    spec = O.amazon_spec(dropout=0.0)
+    rng = np.random.default_rng(2000)
+    masks = [O.random_valid_mask(spec, rng, 0.7) for _ in range(spec.n_domain)]
+    x, y = synth.amazon_batch(spec, rng, 8192, domain=domain_dist)
+    torch.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
+    P = O.init_params(spec, 123)
+    r = O.step(P, spec, x, y, masks, want_grads=(domain_dist == "uniform"))
+    ok = ~np.isnan(r["probs"])
+    refl = r["logits"][ok]
+    cnt = np.bincount(x[:, spec.domain_idx], minlength=spec.n_domain)
+    big = np.broadcast_to((cnt[x[:, spec.domain_idx]] >= 8)[None, :], ok.shape)
+    sel = ok & big
+    assert sel.sum() > 0.99 * ok.sum()
+    # gradient spot checks at this size are sanity bounds (25 per-domain BatchNorm backward passes with cancellation:
+    # the fp32 oracle itself is ~1 % of max away from fp64); strict gradient parity is pinned by the golden tests
+    for precision, gtol in (("f32", 3e-2), ("bf16x3", 6e-2)):
+        model, _ = U.build_model(spec, 123, precision=precision)
+        model.train()
+        md = aread_amd.pack_masks(masks, spec.n_domain, model.edge_num, "cuda")
+        model.domain_mask = [tmask(m) for m in masks]
+        bufs = model.make_step_buffers(8192)
+        loss = model.train_step(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), bufs, masks_dev=md)
+        got = bufs["probs"].cpu().numpy()
+        assert (got[~ok] == 0).all()
+        dl = np.abs(logits_of(got.astype(np.float64)) - r["logits"].astype(np.float64))
+        assert dl[sel].max() <= 1e-4 * max(np.abs(refl).max(), 1.0), (precision, dl[sel].max())
+        assert np.isfinite(got[ok]).all() and np.abs(got[ok & ~big] - r["probs"][ok & ~big]).max(initial=0.0) < 0.2
+        bags = bufs["loss"].cpu().numpy()[1:]
+        for d_, b_ in r["bag_by_domain"].items():
+            if cnt[d_] >= 8:
+                assert abs(bags[d_] - b_) <= 1e-4 * b_, (precision, d_)       # per-domain bagging loss
+        assert abs(float(bufs["reg"][0]) - r["reg"]) <= 2e-5 * r["reg"]
+        if domain_dist == "uniform":
+            assert abs(float(loss) - r["loss"]) <= 5e-5 * abs(r["loss"]), precision
+            g = all_grads(model)
+            for name in ("linear.fc.weight", "cn.w.1.weight", "mmoe_experts.2.layers.4.weight", "mmoe_gates.1.0.weight",
+                         "towers.1.3.layers.0.weight", "tower_gates.1.7.0.weight", "towers_linear.5.weight"):
+                ref = r["grads"][name].numpy()
+                assert np.abs(g[name] - ref).max() <= gtol * np.abs(ref).max(), (precision, name)
+            bag = np.unique(O.index_bag(x, spec))[:4000]
+            gt = model.embedding.embedding_dict.weight.grad[torch.from_numpy(bag.astype(np.int64)).cuda()].cpu().numpy()
+            reft = r["grads"]["embedding.embedding_dict.weight"].numpy()[bag]
+            assert np.abs(gt - reft).max() <= gtol * np.abs(reft).max(), precision
+        del model, bufs
+        torch.cuda.empty_cache()
