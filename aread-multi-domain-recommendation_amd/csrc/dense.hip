@@ -223,7 +223,12 @@ extern "C" int aread_forward(const aread_model* m, const aread_call* c, const fl
     hp.y = c->y; hp.seg_weight = c->seg_weight; hp.dprobs = nullptr;
     hp.loss_part = (c->y && c->loss_out) ? ws + x.w.loss_part : nullptr; hp.level = LL; hp.r = x.r; hp.mp = x.mp;
     LAUNCH(k_heads_fwd, dim3(x.n_tiles * SUB), dim3(256), hp);
-    if (hp.loss_part) LAUNCH(k_loss_finish, dim3(1), dim3(64), ws + x.w.loss_part, c->seg_weight, c->loss_out, x.r);
+    const bool side_tail = hp.loss_part || (c->train && c->update_running);
+    if (side_tail) TRY(fork_side(x));
+    if (hp.loss_part) {
+        hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(64), 0, x.side, ws + x.w.loss_part, c->seg_weight, c->loss_out, x.r);
+        AR_LAUNCH_CHECK();
+    }
     // 8. running statistics, in domain order
     if (c->train && c->update_running) {
         BnRunAllP all = {};
@@ -239,11 +244,10 @@ extern "C" int aread_forward(const aread_model* m, const aread_call* c, const fl
             for (int j = 0; j < m->towers[l].n_layers; ++j) add(m->towers[l].L[j], x.w.tw[l][j], l);
         all.r = x.r; all.mp = x.mp;
         // off the critical path: the statistics buffers are not touched again before the next forward
-        TRY(fork_side(x));
         hipLaunchKernelGGL(k_bn_running, dim3(cdiv(max_cols, 256), all.n_layers), dim3(256), 0, x.side, all);
         AR_LAUNCH_CHECK();
-        TRY(join_side(x));
     }
+    if (side_tail) TRY(join_side(x));
     return AREAD_OK;
 }
 
@@ -365,7 +369,7 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     HeadsP hp = {};
     hp.prob = ws + x.w.prob; hp.dz = ws + x.w.dz; hp.n_heads = m->n_heads; hp.ld_h = m->ld_h; hp.B = c->B;
     hp.y = c->y; hp.seg_weight = c->seg_weight; hp.dprobs = dprobs; hp.level = LL; hp.r = x.r; hp.mp = x.mp;
-    LAUNCH(k_heads_dz, dim3(x.n_tiles * SUB), dim3(256), hp);
+    if (dprobs || !c->y) LAUNCH(k_heads_dz, dim3(x.n_tiles * SUB), dim3(256), hp);   // else: fused into k_heads_fwd
     // 2. heads backward
     const LayerWs& last = x.w.tw[LL][m->towers[LL].n_layers - 1];
     HeadsBwdP hb = {};
@@ -374,8 +378,10 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     hb.part = ws + x.w.misc_part; hb.ldp = 1024; hb.r = x.r;
     AR_CHECK_ARG(m->n_heads * m->h_last <= 1024, "aread_backward: n_heads*h_last too large");
     LAUNCH(k_heads_bwd, dim3(x.n_tiles * SUB), dim3(256), hb);
-    LAUNCH(k_reduce_tiles, dim3(cdiv(m->n_heads * m->h_last, 32)), dim3(256), ws + x.w.misc_part, (int64_t)1024,
-           m->n_heads * m->h_last, grads + m->head_w + D, m->h_last, (int64_t)m->head_ld, 0, SUB, x.r);
+    TRY(fork_side(x));
+    hipLaunchKernelGGL(k_reduce_tiles, dim3(cdiv(m->n_heads * m->h_last, 32)), dim3(256), 0, x.side, ws + x.w.misc_part,
+                       (int64_t)1024, m->n_heads * m->h_last, grads + m->head_w + D, m->h_last, (int64_t)m->head_ld, 0, SUB, x.r);
+    AR_LAUNCH_CHECK();
     // dcn = dz V[:, :D]   and   dV[:, :D] = dz^T cn
     TRY(simple_gemm(x, ws + x.w.dz, m->ld_h, true, P + m->head_w, m->head_ld, false, ws + x.w.dcn, D, nullptr, (int)x.rows, D,
                     m->n_heads, 0, 1));
@@ -399,6 +405,17 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
             LAUNCH(k_mixl_bwd, dim3(x.n_tiles * SUB), dim3(256), mb);
         }
     }
+    // tower-gate input gradient dq = dglogT Tw: ready now, only needed by the row-wise backward -> side stream
+    const hipStream_t main_st0 = x.st;
+    if (m->gate_rows > 0) {
+        TRY(fork_side(x));
+        x.st = x.side;
+        TRY(simple_gemm(x, ws + x.w.dglogT, m->ld_gt, true, P + m->tgate_w, 2 * E, false, ws + x.w.dq, 2 * E, nullptr, (int)x.rows,
+                        2 * E, m->gate_rows, 0, 1));
+        x.st = main_st0;
+    } else {
+        AR_HIP(hipMemsetAsync(ws + x.w.dq, 0, (size_t)x.rows * 2 * E * sizeof(float), x.st));
+    }
     // 4. MMoE mix backward
     const int nle = m->experts.n_layers;
     const LayerL& EL = m->experts.L[nle - 1];
@@ -407,21 +424,26 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     m0.dU = ws + x.w.dIn[0]; m0.dX = ws + x.w.ex[nle - 1].dAct; m0.n_t = cfg.n_tower[0]; m0.n_exp = cfg.n_expert; m0.h = EL.out_dim;
     m0.r = x.r; m0.mp = x.mp;
     LAUNCH(k_mix0_bwd, dim3(x.n_tiles * SUB), dim3(256), m0);
+    // MMoE-gate part of dE (deg = dglogE Gw) on the side stream; the row-wise backward adds it
+    {
+        TRY(fork_side(x));
+        x.st = x.side;
+        TRY(simple_gemm(x, ws + x.w.dglogE, m->ld_ge, true, P + m->gate_w, D, false, ws + x.w.deg, D, nullptr, (int)x.rows, D,
+                        cfg.n_tower[0] * cfg.n_expert, 0, 1));
+        x.st = main_st0;
+    }
+    // the row-wise backward only needs the side stream up to here (dq, deg), not the weight-gradient GEMMs behind it
+    hipEvent_t ev_gates = x.m->ev[x.ev_next++ % (x.m->n_ev - 1)];
+    AR_HIP(hipEventRecord(ev_gates, x.side));
     // 5. experts; the first layer writes de_out
     for (int j = nle - 1; j >= 0; --j) {
         const float* in = j == 0 ? e_in : ws + x.w.ex[j - 1].Act;
         float* d_in = j == 0 ? de_out : ws + x.w.ex[j - 1].dAct;
         TRY(layer_bwd(x, m->experts.L[j], x.w.ex[j], in, d_in, 0, grads, -1, x.w.slab_ex[j]));
     }
-    // 6. gate logits: dE += dglogE Gw, dq = dglogT Tw on the main stream; their weight / bias gradients on the side stream
+    // 6. gate weight / bias gradients (side stream)
     const int n_ge = cfg.n_tower[0] * cfg.n_expert;
     const hipStream_t main_st = x.st;
-    TRY(simple_gemm(x, ws + x.w.dglogE, m->ld_ge, true, P + m->gate_w, D, false, de_out, D, nullptr, (int)x.rows, D, n_ge, 1, 1));
-    if (m->gate_rows > 0)
-        TRY(simple_gemm(x, ws + x.w.dglogT, m->ld_gt, true, P + m->tgate_w, 2 * E, false, ws + x.w.dq, 2 * E, nullptr, (int)x.rows,
-                        2 * E, m->gate_rows, 0, 1));
-    else
-        AR_HIP(hipMemsetAsync(ws + x.w.dq, 0, (size_t)x.rows * 2 * E * sizeof(float), x.st));
     TRY(wgrad(x, ws + x.w.dglogE, m->ld_ge, 0, e_in, D, 0, 1, n_ge, D, grads + m->gate_w, D, 0, nullptr, x.w.slab_gate));
     if (m->gate_rows > 0)
         TRY(wgrad(x, ws + x.w.dglogT, m->ld_gt, 0, ws + x.w.q, 2 * E, 0, 1, m->gate_rows, 2 * E, grads + m->tgate_w, 2 * E, 0, nullptr,
@@ -438,9 +460,10 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
                grads + m->tgate_b, m->gate_rows, (int64_t)0, 0, 1, x.r);
     }
     x.st = main_st;
-    // 7. row-wise trunk backward (adds into de_out): the end of the critical path
+    // 7. row-wise trunk backward (adds into de_out): the end of the critical path; needs dq and deg from the side stream
+    AR_HIP(hipStreamWaitEvent(x.st, ev_gates, 0));
     RowwiseBwdP rb = {};
-    rb.e = e_in; rb.xw = ws + x.w.xw; rb.dcn = ws + x.w.dcn; rb.dlin = ws + x.w.dlin; rb.dq = ws + x.w.dq;
+    rb.e = e_in; rb.xw = ws + x.w.xw; rb.dcn = ws + x.w.dcn; rb.dlin = ws + x.w.dlin; rb.dq = ws + x.w.dq; rb.deg = ws + x.w.deg;
     rb.lin_w = P + m->lin_w; rb.cn_w = P + m->cn_w; rb.cn_b = P + m->cn_b;
     rb.de = de_out; rb.part = ws + x.w.rw_part; rb.part_ld = (int64_t)(2 * cfg.n_cross + 1) * D + 4; rb.dgrp_part = ws + x.w.dgrp_part;
     rb.D = D; rb.E = E; rb.n_cross = cfg.n_cross; rb.dom_field = cfg.domain_field; rb.rows = x.rows; rb.r = x.r;

@@ -503,7 +503,7 @@ __global__ __launch_bounds__(256) void k_mix0_bwd(const Mix0BwdP p) {
 // part layout per tile: [n_cross][D] dw | [n_cross][D] db | [D] dw_lin | 1 db_lin
 // ------------------------------------------------------------------------------------------------
 struct RowwiseBwdP {
-    const float* e; const float* xw; const float* dcn; const float* dlin; const float* dq;
+    const float* e; const float* xw; const float* dcn; const float* dlin; const float* dq; const float* deg;
     const float* lin_w; const float* cn_w; const float* cn_b;
     float* de; float* part; int64_t part_ld; float* dgrp_part;
     int D, E, n_cross, dom_field; int64_t rows;
@@ -593,6 +593,8 @@ __global__ __launch_bounds__(256) void k_rowwise_bwd(const RowwiseBwdP p) {
             if (ch < d4) {
                 const float4 wl = ((const float4*)p.lin_w)[ch];
                 float4 t = o4[ch];
+                const float4 gq = ((const float4*)(p.deg + row * p.D))[ch];       // MMoE-gate part of dE (side stream)
+                t.x += gq.x; t.y += gq.y; t.z += gq.z; t.w += gq.w;
                 t.x += de[v].x + dc[v].x + dl * wl.x; t.y += de[v].y + dc[v].y + dl * wl.y;
                 t.z += de[v].z + dc[v].z + dl * wl.z; t.w += de[v].w + dc[v].w + dl * wl.w;
                 // domain-embedding part of the gate input

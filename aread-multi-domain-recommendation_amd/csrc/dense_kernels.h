@@ -449,8 +449,20 @@ __global__ __launch_bounds__(256) void k_heads_fwd(const HeadsP p) {
         }
         p.z[row * p.ld_h + i] = z;
         p.prob[row * p.ld_h + i] = pr;
-        (void)dz;
+        if (p.y) {                                    // fused loss gradient (BCELoss backward * sigmoid backward)
+            if (on) {
+                const float wseg = p.seg_weight ? p.seg_weight[seg] : 1.f;
+                const float dp = wseg / (cnt * kact) * (pr - p.y[p.r.row_sample[row]]) / fmaxf((1.0f - pr) * pr, 1e-12f);
+                dz = dp * pr * (1.0f - pr);
+            }
+            p.dz[row * p.ld_h + i] = dz;
+        }
     }
+    if (p.y)                                          // pad columns of dz
+        for (int it = threadIdx.x; it < SUB_ROWS * (p.ld_h - p.n_heads); it += 256) {
+            const int rr = r_lo + it / (p.ld_h - p.n_heads), i = p.n_heads + it % (p.ld_h - p.n_heads);
+            p.dz[((int64_t)tile * TILE_M + rr) * p.ld_h + i] = 0.f;
+        }
     if (p.loss_part) {
         s_loss[threadIdx.x] = loss;
         __syncthreads();

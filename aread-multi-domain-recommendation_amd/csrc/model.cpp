@@ -221,6 +221,7 @@ void ws_layout(const aread_model* m, int64_t B, int n_seg, WsLayout* w) {
     w->max_rows = rows; w->n_tiles = tiles;
     w->cn = take(&o, rows * D);
     w->dcn = take(&o, rows * D);
+    w->deg = take(&o, rows * D);
     w->lin = take(&o, rows);
     w->dlin = take(&o, rows);
     w->xw = take(&o, (int64_t)MAX_CROSS * rows);

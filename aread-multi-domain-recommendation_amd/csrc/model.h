@@ -60,7 +60,7 @@ int model_streams_init(const aread_model* m);
 
 struct WsLayout {                            // float offsets into the workspace (computed per (B, n_seg))
     int64_t max_rows, n_tiles;
-    int64_t cn, lin, xw, q, glogE, glogT, hc, z, prob, dz, dlin, dcn, dq, dglogE, dglogT, grp, dgrp_part;
+    int64_t cn, lin, xw, q, glogE, glogT, hc, z, prob, dz, dlin, dcn, dq, deg, dglogE, dglogT, grp, dgrp_part;
     int64_t In[AREAD_MAX_LEVEL], dIn[AREAD_MAX_LEVEL];
     LayerWs ex[AREAD_MAX_LAYER];
     LayerWs tw[AREAD_MAX_LEVEL][AREAD_MAX_LAYER];

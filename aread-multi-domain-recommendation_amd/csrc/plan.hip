@@ -4,15 +4,16 @@
 
 #define PLAN_THREADS 1024
 
-// One workgroup.  Pass 1: integer histogram (LDS atomics: order-independent, deterministic).
-// Pass 2: stable rank of every sample inside its segment via wave ballots + per-wave LDS counts.
+// One workgroup of 16 waves.  Wave w owns the contiguous sample range [w*C, (w+1)*C): pass 1 counts its samples per
+// segment (ballot + popcount, no atomics), a prefix over waves gives every wave its first row per segment, pass 2
+// assigns rows in sample order with wave-private running counters.  Stable and deterministic; three block barriers.
 __global__ __launch_bounds__(PLAN_THREADS) void k_plan_build(const int32_t* __restrict__ x, int B, int f_in,
                                                               int seg_col, int n_seg, int32_t* __restrict__ plan,
                                                               int max_rows, int max_tiles) {
-    __shared__ int s_count[MAX_SEG];
+    constexpr int NW = PLAN_THREADS / WAVE;
+    __shared__ int s_cnt[NW][MAX_SEG];       // pass 1: samples of wave w in segment s; pass 2: next row
     __shared__ int s_start[MAX_SEG];
-    __shared__ int s_run[MAX_SEG];                      // rows already placed per segment
-    __shared__ int s_wave[PLAN_THREADS / WAVE][MAX_SEG];  // per-wave counts of the current chunk
+    __shared__ int s_total[MAX_SEG];
     __shared__ int s_bad;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int32_t* seg_count = plan + PLAN_HDR;
@@ -21,33 +22,51 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_build(const int32_t* __re
     int32_t* tile_valid = tile_seg + max_tiles;
     int32_t* row_sample = tile_valid + max_tiles;
     int32_t* sample_row = row_sample + max_rows;
+    const int chunk = ((B + NW - 1) / NW + WAVE - 1) / WAVE * WAVE;
+    const int b0 = wave * chunk, b1 = min(B, b0 + chunk);
 
-    if (tid < MAX_SEG) { s_count[tid] = 0; s_run[tid] = 0; }
+    for (int i = lane; i < MAX_SEG; i += WAVE) s_cnt[wave][i] = 0;
     if (tid == 0) s_bad = 0;
     for (int i = tid; i < max_rows; i += PLAN_THREADS) row_sample[i] = -1;
     for (int i = tid; i < max_tiles; i += PLAN_THREADS) { tile_seg[i] = -1; tile_valid[i] = 0; }
     __syncthreads();
-    for (int b = tid; b < B; b += PLAN_THREADS) {
-        int s = 0;
-        if (seg_col >= 0) {
-            s = x[(int64_t)b * f_in + seg_col];
-            if (s < 0 || s >= n_seg) { atomicAdd(&s_bad, 1); s = s < 0 ? 0 : n_seg - 1; }
+    auto seg_of = [&](int b) -> int {
+        if (b >= b1) return -1;
+        if (seg_col < 0) return 0;
+        int s = x[(int64_t)b * f_in + seg_col];
+        if (s < 0 || s >= n_seg) { atomicAdd(&s_bad, 1); s = s < 0 ? 0 : n_seg - 1; }
+        return s;
+    };
+    for (int base = b0; base < b1; base += WAVE) {                 // pass 1
+        const int s = seg_of(base + lane);
+        unsigned long long todo = __ballot(s >= 0);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int s0 = __shfl(s, leader);
+            const unsigned long long same = __ballot(s == s0);
+            if (lane == leader) s_cnt[wave][s0] += __popcll(same);
+            todo &= ~same;
         }
-        atomicAdd(&s_count[s], 1);
+    }
+    __syncthreads();
+    if (tid < MAX_SEG) {                                           // per segment: total and exclusive prefix over waves
+        int run = 0;
+        for (int w = 0; w < NW; ++w) { const int c = s_cnt[w][tid]; s_cnt[w][tid] = run; run += c; }
+        s_total[tid] = tid < n_seg ? run : 0;
     }
     __syncthreads();
     if (tid == 0) {
         int row = 0;
         for (int s = 0; s < MAX_SEG; ++s) {
-            int c = s < n_seg ? s_count[s] : 0;
+            const int c = s_total[s];
             s_start[s] = row;
             seg_count[s] = c;
             seg_start[s] = row;
-            int nt = (c + TILE_M - 1) / TILE_M;
+            const int nt = (c + TILE_M - 1) / TILE_M;
             for (int t = 0; t < nt; ++t) {
-                int ti = row / TILE_M + t;
+                const int ti = row / TILE_M + t;
                 tile_seg[ti] = s;
-                int v = c - t * TILE_M;
+                const int v = c - t * TILE_M;
                 tile_valid[ti] = v > TILE_M ? TILE_M : v;
             }
             row += nt * TILE_M;
@@ -56,46 +75,25 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_build(const int32_t* __re
         plan[PLAN_NSEG] = n_seg;
         plan[PLAN_ROWS] = row;
         plan[PLAN_NTILES] = row / TILE_M;
-        plan[PLAN_NBAD] = s_bad;
+        plan[PLAN_NBAD] = s_bad / 2;                               // every sample is classified twice
     }
     __syncthreads();
-    for (int base = 0; base < B; base += PLAN_THREADS) {
-        const int b = base + tid;
-        int s = -1;
-        if (b < B) {
-            s = 0;
-            if (seg_col >= 0) {
-                s = x[(int64_t)b * f_in + seg_col];
-                s = s < 0 ? 0 : (s >= n_seg ? n_seg - 1 : s);
-            }
-        }
-        for (int i = lane; i < MAX_SEG; i += WAVE) s_wave[wave][i] = 0;
-        // rank inside the wave among equal segment ids
-        int rank_in_wave = 0;
+    for (int base = b0; base < b1; base += WAVE) {                 // pass 2
+        const int b = base + lane;
+        const int s = seg_of(b);
         unsigned long long todo = __ballot(s >= 0);
         while (todo) {
-            int leader = __ffsll((long long)todo) - 1;
-            int s0 = __shfl(s, leader);
-            unsigned long long same = __ballot(s == s0);
-            if (s == s0) rank_in_wave = __popcll(same & ((1ull << lane) - 1ull));
-            if (lane == leader) s_wave[wave][s0] = __popcll(same);
+            const int leader = __ffsll((long long)todo) - 1;
+            const int s0 = __shfl(s, leader);
+            const unsigned long long same = __ballot(s == s0);
+            if (s == s0) {
+                const int r = s_start[s0] + s_cnt[wave][s0] + __popcll(same & ((1ull << lane) - 1ull));
+                row_sample[r] = b;
+                sample_row[b] = r;
+            }
+            if (lane == leader) s_cnt[wave][s0] += __popcll(same);
             todo &= ~same;
         }
-        __syncthreads();
-        if (b < B) {
-            int before = 0;
-            for (int w = 0; w < wave; ++w) before += s_wave[w][s];
-            int r = s_start[s] + s_run[s] + before + rank_in_wave;
-            row_sample[r] = b;
-            sample_row[b] = r;
-        }
-        __syncthreads();
-        if (tid < MAX_SEG) {
-            int add = 0;
-            for (int w = 0; w < PLAN_THREADS / WAVE; ++w) add += s_wave[w][tid];
-            s_run[tid] += add;
-        }
-        __syncthreads();
     }
 }
 

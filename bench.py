@@ -198,6 +198,8 @@ def main():
     gemm = measure_gemm_kernel(model, bufs, L, B, args.precision)
     l2pass = measure_l2_kernel(model, bufs, L)
     gather = measure_gather_kernel(model, xs, bufs, L)
+    big_x = torch.cat([bt[0] for bt in batches] * 2, dim=0)                  # 65 536 samples: latency amortised
+    gather_big = measure_gather_kernel(model, big_x, bufs, L)
     # `roofline` = the single most expensive kernel launch of the step (longest average duration, cf. profiles/)
     roofline = max((gemm, l2pass), key=lambda r: r["avg_launch_us"])
 
@@ -215,6 +217,7 @@ def main():
                    "parallelism": f"dp{world}" + (": replicated table, all_gather(ids,dE)+all_reduce(dense grads) over RCCL"
                                                    if use_dp else "")},
         "roofline": roofline, "gemm_roofline": gemm, "l2_table_roofline": l2pass, "gather_roofline": gather,
+        "gather_roofline_b65536": gather_big,
         "loss": round(loss, 6),
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -312,7 +315,7 @@ def measure_gather_kernel(model, xs, bufs, L):
     ach = per_sample * B / t / 1e9
     return {"kernel": "k_embed_fwd", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4), "read_stream_frac": round(read_stream * B / t / 1e9 / HBM_PEAK_GBS, 4),
-            "traffic": _pmc_traffic("k_embed_fwd"),
+            "traffic": _pmc_traffic("k_embed_fwd") if B == 8192 else None, "samples": B,
             "algorithmic_bytes_per_launch": per_sample * B, "avg_launch_us": round(t * 1e6, 2)}
 
 
