@@ -127,24 +127,55 @@ struct TileLoader {
 
 // ---- epilogue shared by the fp32 and the split-bf16 kernels ----------------------------------------------
 // C/D layout of every 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg.
+// s_c: per-wave staging area of 16 x (16*NI + 4) floats (the k-loop's LDS tiles are dead by now and are reused).
 template <int NI>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[NI], int g, int ks, int m0, int n0, int by,
-                                              float (*s_red)[16 * NI]) {
+                                              float (*s_red)[16 * NI], float* s_c) {
+    constexpr int TN = 16 * NI, CP = TN + 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col_in = lane & 15, row_base = wave * 16 + (lane >> 4) * 4;
     float* Cg = p.C + (int64_t)g * p.c_gs + (int64_t)ks * p.c_ks;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int n = n0 + i * 16 + col_in;
-        if (n < p.N) {
-            const float bv = p.bias ? p.bias[(int64_t)g * p.bias_gs + n] : 0.f;
+        const float bv = (p.bias && n < p.N) ? p.bias[(int64_t)g * p.bias_gs + n] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                acc[i][r] += bv;
-                const int m = m0 + row_base + r;
-                if (m < p.M) {
-                    float* c = Cg + (int64_t)m * p.ldc + n;
-                    *c = p.accumulate ? *c + acc[i][r] : acc[i][r];
+        for (int r = 0; r < 4; ++r) acc[i][r] += bv;
+    }
+    const bool vec_ok = (n0 + TN <= p.N) && (m0 + 64 <= p.M) && ((p.ldc & 3) == 0) && ((p.c_gs & 3) == 0) &&
+                        ((p.c_ks & 3) == 0) && (((uintptr_t)p.C & 15) == 0);
+    if (vec_ok) {
+        // C/D fragment (col = lane&15, rows (lane>>4)*4 + r) -> LDS [16][CP] -> 16-byte row segments to global
+        float* sw = s_c + wave * 16 * CP;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sw[((lane >> 4) * 4 + r) * CP + i * 16 + col_in] = acc[i][r];
+        __builtin_amdgcn_wave_barrier();
+        constexpr int Q = TN / 4;                       // float4 per row
+#pragma unroll
+        for (int it = 0; it < (16 * Q + 63) / 64; ++it) {
+            const int idx = it * 64 + lane;
+            if (idx < 16 * Q) {
+                const int rr = idx / Q, c4 = idx - rr * Q;
+                float4 v = *(const float4*)(sw + rr * CP + c4 * 4);
+                float4* dst = (float4*)(Cg + (int64_t)(m0 + wave * 16 + rr) * p.ldc + n0 + c4 * 4);
+                if (p.accumulate) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                *dst = v;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int n = n0 + i * 16 + col_in;
+            if (n < p.N) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + row_base + r;
+                    if (m < p.M) {
+                        float* c = Cg + (int64_t)m * p.ldc + n;
+                        *c = p.accumulate ? *c + acc[i][r] : acc[i][r];
+                    }
                 }
             }
         }
@@ -204,8 +235,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm(const GemmP p) {
     constexpr int TM = 64, TN = 16 * NI;
     using LA = TileLoader<TM, A_KC>;
     using LB = TileLoader<TN, B_KC>;
-    __shared__ __attribute__((aligned(16))) float As[LA::LDS_FLOATS];
-    __shared__ __attribute__((aligned(16))) float Bs[LB::LDS_FLOATS];
+    constexpr int STAGE = 4 * 16 * (TN + 4);            // epilogue staging (floats), overlays the operand tiles
+    constexpr int OPER = LA::LDS_FLOATS + LB::LDS_FLOATS;
+    __shared__ __attribute__((aligned(16))) float s_lds[OPER > STAGE ? OPER : STAGE];
+    float* As = s_lds;
+    float* Bs = s_lds + LA::LDS_FLOATS;
     __shared__ float s_red[4][TN];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -287,7 +321,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm(const GemmP p) {
         k0 = kn;
     }
 
-    gemm_epilogue<NI>(p, acc, g, ks, m0, n0, by, s_red);
+    gemm_epilogue<NI>(p, acc, g, ks, m0, n0, by, s_red, s_lds);
 }
 
 // ================================================================================================
@@ -357,8 +391,13 @@ struct Bf3Loader {
 template <int NI>
 __global__ __launch_bounds__(GEMM_THREADS) void k_gemm_bf3(const GemmP p) {
     constexpr int TM = 64, TN = 16 * NI;
-    __shared__ __attribute__((aligned(16))) __bf16 Ah[TM * BF3_PITCH], Al[TM * BF3_PITCH];
-    __shared__ __attribute__((aligned(16))) __bf16 Bh[TN * BF3_PITCH], Bl[TN * BF3_PITCH];
+    constexpr int STAGE_B = 4 * 16 * (TN + 4) * 4;       // epilogue staging (bytes), overlays the operand tiles
+    constexpr int OPER_B = 2 * (TM + TN) * BF3_PITCH * 2;
+    __shared__ __attribute__((aligned(16))) char s_lds[OPER_B > STAGE_B ? OPER_B : STAGE_B];
+    __bf16* Ah = (__bf16*)s_lds;
+    __bf16* Al = Ah + TM * BF3_PITCH;
+    __bf16* Bh = Al + TM * BF3_PITCH;
+    __bf16* Bl = Bh + TN * BF3_PITCH;
     __shared__ float s_red[4][TN];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -419,7 +458,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm_bf3(const GemmP p) {
         }
         __syncthreads();
     }
-    gemm_epilogue<NI>(p, acc, g, 0, m0, n0, by, s_red);
+    gemm_epilogue<NI>(p, acc, g, 0, m0, n0, by, s_red, (float*)s_lds);
 }
 
 // number of 16-column MFMA tiles per wave: 96-wide tiles when they cover N with less padding than 128-wide ones
