@@ -256,19 +256,25 @@ extern "C" int aread_forward(const aread_model* m, const aread_call* c, const fl
 // ================================================================================================
 static int wgrad(Ctx& x, const float* dY, int64_t ld_dy, int64_t dy_gs, const float* X, int64_t ldx, int64_t x_gs, int G,
                  int M, int N, float* out, int64_t ldo, int64_t o_gs, const uint8_t* active, int64_t slab_off) {
-    const KSplit ks = wgrad_ksplit(x.rows, G, M, N);
+    // dW[M][N] = dY^T X.  A skinny M (a handful of gate / head rows) would waste most of the 64-row MFMA tile:
+    // compute the transposed product X^T dY instead (M plays the 16-wide N role) and let the reduction write it back
+    // transposed.
+    const bool swap = M <= 16 && N > 16 && G == 1;
+    const int Mg = swap ? N : M, Ng = swap ? M : N;
+    const KSplit ks = wgrad_ksplit(x.rows, G, Mg, Ng);
     GemmP g = {};
-    g.A = dY; g.lda = ld_dy; g.a_gs = dy_gs;
-    g.B = X; g.ldb = ldx; g.b_gs = x_gs;
-    g.C = x.ws + slab_off; g.ldc = N; g.c_gs = (int64_t)M * N; g.c_ks = (int64_t)G * M * N;
-    g.M = M; g.N = N; g.K = (int)x.rows; g.G = G;
+    g.A = swap ? X : dY; g.lda = swap ? ldx : ld_dy; g.a_gs = swap ? x_gs : dy_gs;
+    g.B = swap ? dY : X; g.ldb = swap ? ld_dy : ldx; g.b_gs = swap ? dy_gs : x_gs;
+    g.C = x.ws + slab_off; g.ldc = Ng; g.c_gs = (int64_t)Mg * Ng; g.c_ks = (int64_t)G * Mg * Ng;
+    g.M = Mg; g.N = Ng; g.K = (int)x.rows; g.G = G;
     g.k_split = ks.k_split; g.k_chunk = ks.k_chunk;
     g.gate_axis = 2; g.tile_seg = x.r.tile_seg; g.tile_valid = x.r.tile_valid; g.active = active; g.active_ld = MAX_TOWER;
     TRY(fork_side(x));                                   // everything this wgrad reads has been issued on the main stream
     TRY(launch_gemm(g, false, false, x.side));
     AR_CHECK_ARG(x.splitk.n < MAX_WGRADS, "too many wgrads");
     SplitKOne& d = x.splitk.d[x.splitk.n++];
-    d.slab = x.ws + slab_off; d.out = out; d.k_split = ks.k_split; d.G = G; d.M = M; d.N = N; d.ldo = ldo; d.o_gs = o_gs;
+    d.slab = x.ws + slab_off; d.out = out; d.k_split = ks.k_split; d.G = G; d.M = Mg; d.N = Ng; d.ldo = ldo; d.o_gs = o_gs;
+    d.transposed = swap ? 1 : 0;
     return AREAD_OK;
 }
 

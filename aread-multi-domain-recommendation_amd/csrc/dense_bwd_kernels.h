@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void k_transpose_weights(const TransAllP a) {
 }
 
 // batched split-K reduction: for every wgrad d, out[g][m][n] = sum_ks slab[ks][g][m][n]  (grid.y = d)
-struct SplitKOne { const float* slab; float* out; int k_split, G, M, N; int64_t ldo, o_gs; };
+struct SplitKOne { const float* slab; float* out; int k_split, G, M, N; int64_t ldo, o_gs; int transposed; };
 #define MAX_WGRADS 24
 struct SplitKAllP { int n; SplitKOne d[MAX_WGRADS]; };
 __global__ __launch_bounds__(256) void k_splitk_reduce_all(const SplitKAllP a) {
@@ -114,7 +114,8 @@ __global__ __launch_bounds__(256) void k_splitk_reduce_all(const SplitKAllP a) {
             const int g = (int)(idx / ((int64_t)p.M * p.N));
             const int rem = (int)(idx - (int64_t)g * p.M * p.N);
             const int m = rem / p.N, n = rem - m * p.N;
-            p.out[(int64_t)g * p.o_gs + (int64_t)m * p.ldo + n] = tot;
+            if (p.transposed) p.out[(int64_t)g * p.o_gs + (int64_t)n * p.ldo + m] = tot;   // slab holds the transposed product
+            else p.out[(int64_t)g * p.o_gs + (int64_t)m * p.ldo + n] = tot;
         }
         __syncthreads();
     }

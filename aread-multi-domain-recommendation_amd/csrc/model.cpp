@@ -251,7 +251,10 @@ void ws_layout(const aread_model* m, int64_t B, int n_seg, WsLayout* w) {
     w->loss_part = take(&o, tiles * 4);
     w->gate_part = take(&o, tiles * 4 * m->ld_gt);
     // split-K slabs, one region per wgrad so that all of them can be reduced by one launch at the end
-    auto slab = [&](int G, int M, int N) { return take(&o, (int64_t)G * M * N * wgrad_ksplit(rows, G, M, N).k_split); };
+    auto slab = [&](int G, int M, int N) {       // dense.hip::wgrad swaps the roles of a skinny M (<= 16) and N
+        const bool swap = M <= 16 && N > 16 && G == 1;
+        return take(&o, (int64_t)G * M * N * wgrad_ksplit(rows, G, swap ? N : M, swap ? M : N).k_split);
+    };
     for (int j = 0; j < m->experts.n_layers; ++j) {
         const LayerL& L = m->experts.L[j];
         w->slab_ex[j] = (L.in_gs == 0 && L.G > 1) ? slab(1, L.ncols, L.in_dim) : slab(L.G, L.out_dim, L.in_dim);
@@ -370,7 +373,7 @@ void mlp_ws_layout(const aread_model* m, int64_t B, WsLayout* w) {
         const LayerL& L = m->experts.L[j];
         w->slab_ex[j] = take(&o, (int64_t)L.out_dim * L.in_dim * wgrad_ksplit(rows, 1, L.out_dim, L.in_dim).k_split);
     }
-    w->slab_head = take(&o, (int64_t)m->h_last * wgrad_ksplit(rows, 1, 1, m->h_last).k_split + 64);
+    w->slab_head = take(&o, (int64_t)m->h_last * wgrad_ksplit(rows, 1, m->h_last > 16 ? m->h_last : 1, m->h_last > 16 ? 1 : m->h_last).k_split + 64);
     w->active = take(&o, (int64_t)AREAD_MAX_LEVEL * MAX_SEG * MAX_TOWER / 4);
     w->kact = take(&o, 2 * MAX_SEG);
     w->seg_dom = take(&o, MAX_SEG);
