@@ -3,6 +3,7 @@
 #include "common.h"
 
 #define PLAN_THREADS 1024
+#define PLAN_REGS 8
 
 // One workgroup of 16 waves.  Wave w owns the contiguous sample range [w*C, (w+1)*C): pass 1 counts its samples per
 // segment (ballot + popcount, no atomics), a prefix over waves gives every wave its first row per segment, pass 2
@@ -30,24 +31,37 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_build(const int32_t* __re
     for (int i = tid; i < max_rows; i += PLAN_THREADS) row_sample[i] = -1;
     for (int i = tid; i < max_tiles; i += PLAN_THREADS) { tile_seg[i] = -1; tile_valid[i] = 0; }
     __syncthreads();
-    auto seg_of = [&](int b) -> int {
-        if (b >= b1) return -1;
-        if (seg_col < 0) return 0;
-        int s = x[(int64_t)b * f_in + seg_col];
-        if (s < 0 || s >= n_seg) { atomicAdd(&s_bad, 1); s = s < 0 ? 0 : n_seg - 1; }
-        return s;
-    };
-    for (int base = b0; base < b1; base += WAVE) {                 // pass 1
-        const int s = seg_of(base + lane);
-        unsigned long long todo = __ballot(s >= 0);
-        while (todo) {
-            const int leader = __ffsll((long long)todo) - 1;
-            const int s0 = __shfl(s, leader);
-            const unsigned long long same = __ballot(s == s0);
-            if (lane == leader) s_cnt[wave][s0] += __popcll(same);
-            todo &= ~same;
+    // the wave's segment ids are fetched in batches of PLAN_REGS x 64 with all loads in flight at once (the id column
+    // is strided by f_in*4 bytes: one load latency per batch instead of one per 64 samples) and reused by both passes
+    auto load_batch = [&](int base, int (&sg)[PLAN_REGS]) {
+#pragma unroll
+        for (int j = 0; j < PLAN_REGS; ++j) {
+            const int b = base + j * WAVE + lane;
+            int s = -1;
+            if (b < b1) {
+                s = 0;
+                if (seg_col >= 0) {
+                    s = x[(int64_t)b * f_in + seg_col];
+                    if (s < 0 || s >= n_seg) { atomicAdd(&s_bad, 1); s = s < 0 ? 0 : n_seg - 1; }
+                }
+            }
+            sg[j] = s;
         }
+    };
+    const bool single_batch = (b1 - b0) <= PLAN_REGS * WAVE;
+    int sg[PLAN_REGS];
+    // Lane L keeps the counter of segment L in a register (MAX_SEG == wave size); one ballot per segment value.
+    int my_cnt = 0;
+    for (int base = b0; base < b1; base += PLAN_REGS * WAVE) {     // pass 1: count
+        load_batch(base, sg);
+#pragma unroll
+        for (int j = 0; j < PLAN_REGS; ++j)
+            for (int v = 0; v < n_seg; ++v) {
+                const unsigned long long m = __ballot(sg[j] == v);
+                if (lane == v) my_cnt += __popcll(m);
+            }
     }
+    s_cnt[wave][lane] = my_cnt;
     __syncthreads();
     if (tid < MAX_SEG) {                                           // per segment: total and exclusive prefix over waves
         int run = 0;
@@ -75,24 +89,31 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_build(const int32_t* __re
         plan[PLAN_NSEG] = n_seg;
         plan[PLAN_ROWS] = row;
         plan[PLAN_NTILES] = row / TILE_M;
-        plan[PLAN_NBAD] = s_bad / 2;                               // every sample is classified twice
+        plan[PLAN_NBAD] = single_batch ? s_bad : s_bad / 2;        // re-loaded batches classify every sample twice
     }
     __syncthreads();
-    for (int base = b0; base < b1; base += WAVE) {                 // pass 2
-        const int b = base + lane;
-        const int s = seg_of(b);
-        unsigned long long todo = __ballot(s >= 0);
-        while (todo) {
-            const int leader = __ffsll((long long)todo) - 1;
-            const int s0 = __shfl(s, leader);
-            const unsigned long long same = __ballot(s == s0);
-            if (s == s0) {
-                const int r = s_start[s0] + s_cnt[wave][s0] + __popcll(same & ((1ull << lane) - 1ull));
+    int run = s_start[lane] + s_cnt[wave][lane];                   // next row of segment `lane` for this wave
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int base = b0; base < b1; base += PLAN_REGS * WAVE) {     // pass 2: assign rows in sample order
+        if (!single_batch) load_batch(base, sg);
+#pragma unroll
+        for (int j = 0; j < PLAN_REGS; ++j) {
+            const int b = base + j * WAVE + lane;
+            const int s = sg[j];
+            unsigned long long mine = 0ull;
+            int add = 0;
+            for (int v = 0; v < n_seg; ++v) {
+                const unsigned long long m = __ballot(s == v);
+                if (s == v) mine = m;
+                if (lane == v) add = __popcll(m);
+            }
+            const int first = __shfl(run, s < 0 ? 0 : s);
+            if (s >= 0) {
+                const int r = first + __popcll(mine & lt);
                 row_sample[r] = b;
                 sample_row[b] = r;
             }
-            if (lane == leader) s_cnt[wave][s0] += __popcll(same);
-            todo &= ~same;
+            run += add;
         }
     }
 }
