@@ -33,6 +33,8 @@ _SIGS = {
     "aread_embed_bwd_sort": (C.c_int, [i32p, C.c_int64, C.c_int, i32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, i32p, vp, vp]),
     "aread_embed_bwd_reduce": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.c_int, f32p, f32p, vp, vp]),
+    "aread_route_ws_bytes": (C.c_int64, [C.c_int64, C.c_int]),
+    "aread_route_build": (C.c_int, [i32p, C.c_int64, C.c_int, i32p, C.c_int64, C.c_int, vp, i32p, i32p, i32p, vp]),
     "aread_l2_partials": (C.c_int, []),
     "aread_l2_table": (C.c_int, [f32p, C.c_int64, C.c_float, C.c_float, f32p, f32p, vp]),
     "aread_l2_finish": (C.c_int, [f32p, C.c_int, C.c_float, f32p, C.c_int, vp]),

@@ -405,8 +405,9 @@ class AREAD(HempMixin, nn.Module):
         return pack_masks(masks, self.n_domain, self._edge_count, device)
 
     def _run(self, x, mode_id, n_seg, domain, masks_dev, want_gates, y=None, seg_weight=None, loss_out=None,
-             ws=None, plan=None, probs=None, e=None):
-        """plan + embedding + dense forward.  Returns a _CallState (buffers owned by it)."""
+             ws=None, plan=None, probs=None, e=None, e_ready=False):
+        """plan + embedding + dense forward.  Returns a _CallState (buffers owned by it).
+        e_ready: `e` already holds the pooled embedding in plan order (row-sharded table, dist.ShardedTableStep)."""
         L.require_device(x, self.dense, self.embedding.embedding_dict.weight)
         L.require(x, torch.int32, "x")
         lib = L.lib()
@@ -418,10 +419,11 @@ class AREAD(HempMixin, nn.Module):
         emb = self.embedding
         st.e = e if e is not None else torch.empty((st.plan.max_rows, self.embed_output_dim), dtype=torch.float32,
                                                    device=x.device)
-        L.check(lib.aread_embed_fwd(L.ptr(x), B, x.shape[1], L.ptr(emb._offsets_dev(x.device)), L.ptr(table),
-                                    table.shape[0], emb.embed_dim, emb.one_hot_field_num, emb.multi_hot_field_num,
-                                    emb.seq_maxlen, emb._pool, L.ptr(st.plan.row_sample), st.plan.max_rows, L.ptr(st.e),
-                                    None, L.stream()))
+        if not e_ready:
+            L.check(lib.aread_embed_fwd(L.ptr(x), B, x.shape[1], L.ptr(emb._offsets_dev(x.device)), L.ptr(table),
+                                        table.shape[0], emb.embed_dim, emb.one_hot_field_num, emb.multi_hot_field_num,
+                                        emb.seq_maxlen, emb._pool, L.ptr(st.plan.row_sample), st.plan.max_rows,
+                                        L.ptr(st.e), None, L.stream()))
         if ws is None:
             nbytes = lib.aread_model_workspace_bytes(self._handle, B, n_seg)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
@@ -533,7 +535,7 @@ class AREAD(HempMixin, nn.Module):
             self.eval_loss[d] = []
 
     # ---- fused training step (extension; what bench.py times) -------------------------------------------
-    def make_step_buffers(self, B, multi_domain=True, device=None):
+    def make_step_buffers(self, B, multi_domain=True, device=None, with_table_grad=True):
         device = device or self.dense.device
         n_seg = self.n_domain if multi_domain else 1
         lib = L.lib()
@@ -549,7 +551,7 @@ class AREAD(HempMixin, nn.Module):
             reg=torch.zeros(257, dtype=torch.float32, device=device),
             total=torch.zeros(1, dtype=torch.float32, device=device),
             gdense=torch.zeros_like(self.dense),
-            gtable=torch.empty_like(self.embedding.embedding_dict.weight.data),
+            gtable=torch.empty_like(self.embedding.embedding_dict.weight.data) if with_table_grad else None,
         )
         return bufs
 
@@ -560,15 +562,17 @@ class AREAD(HempMixin, nn.Module):
         return self._streams[key]
 
     def step_local(self, x, y, bufs, masks_dev=None, domain_i=None, seg_weight=None, with_reg=True,
-                   with_dense_l2=True, want_gates=False, presort=True, plan=None):
+                   with_dense_l2=True, want_gates=False, presort=True, plan=None, e_ready=False, l2_target=None):
         """Rank-local part of the step: row plan, gather, dense forward + bagging BCE + backward on the current
         stream; concurrently on a side stream (fork-join, capturable): the table L2 pass
         (bufs['gtable'] = 2*l2*W, bufs['reg'] = l2 terms) and, with presort, the index sort of the embedding
         backward.  Leaves bufs['de'] (gradient w.r.t. the pooled embedding, plan order) for step_scatter.
-        No host sync, no allocation besides the row plan."""
+        No host sync, no allocation besides the row plan.
+        e_ready / l2_target=(rows, grad): row-sharded table -- bufs['e'] is already filled and the L2 pass runs over
+        this rank's shard instead of the full table."""
         lib = L.lib()
         n_seg = bufs["n_seg"]
-        table = self.embedding.embedding_dict.weight
+        table, gtable = (self.embedding.embedding_dict.weight, bufs["gtable"]) if l2_target is None else l2_target
         if masks_dev is None:
             masks_dev = self._masks_dev(self.domain_mask, x.device)
         if plan is None:
@@ -579,17 +583,18 @@ class AREAD(HempMixin, nn.Module):
         side.wait_stream(main)
         with torch.cuda.stream(side):
             if with_reg:
-                L.check(lib.aread_l2_table(L.ptr(table), table.numel(), self.l2_reg_embedding, 1.0, L.ptr(bufs["gtable"]),
+                L.check(lib.aread_l2_table(L.ptr(table), table.numel(), self.l2_reg_embedding, 1.0, L.ptr(gtable),
                                            L.ptr(part), L.stream()))
                 L.check(lib.aread_l2_finish(L.ptr(part), part.numel(), self.l2_reg_embedding, L.ptr(bufs["reg"]), 0,
                                             L.stream()))
             else:
-                bufs["gtable"].zero_()
+                gtable.zero_()
                 bufs["reg"].zero_()
             if presort:
                 self.embedding.sort_lookups(x, plan.sample_row)
         st, gate = self._run(x, 0, n_seg, domain_i, masks_dev, want_gates, y=y, seg_weight=seg_weight,
-                             loss_out=bufs["loss"], ws=bufs["ws"], probs=bufs["probs"], e=bufs["e"], plan=plan)
+                             loss_out=bufs["loss"], ws=bufs["ws"], probs=bufs["probs"], e=bufs["e"], plan=plan,
+                             e_ready=e_ready)
         st.call.async_tail = 1          # parameter gradients finish on the library's side stream: see step_finish
         L.check(lib.aread_backward(self._handle, C.byref(st.call), L.ptr(st.e), None, L.ptr(bufs["gdense"]),
                                    L.ptr(bufs["de"]), L.stream()))

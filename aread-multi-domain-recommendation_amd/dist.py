@@ -18,6 +18,17 @@ import torch
 import torch.distributed as dist
 
 
+_REBASE = {}
+
+
+def _rebase(world, B, rows, dtype, device):
+    """[r*rows for r in range(world) for _ in range(B)] -- constant per configuration, built once"""
+    key = (world, B, rows, dtype, str(device))
+    if key not in _REBASE:
+        _REBASE[key] = (torch.arange(world, device=device, dtype=dtype) * rows).repeat_interleave(B)
+    return _REBASE[key]
+
+
 def gather_ids(x, sample_row, rows, group=None):
     """all_gather the id matrix and the row map; the row map of rank r is rebased by r*rows so that it indexes the
     concatenation of every rank's dE buffer.  Returns (x_all [P*B,F], sample_row_all [P*B])."""
@@ -27,7 +38,7 @@ def gather_ids(x, sample_row, rows, group=None):
     sr_all = torch.empty(world * B, dtype=sample_row.dtype, device=x.device)
     dist.all_gather_into_tensor(x_all, x.contiguous(), group=group)
     dist.all_gather_into_tensor(sr_all, sample_row.contiguous(), group=group)
-    sr_all += (torch.arange(world, device=x.device, dtype=sr_all.dtype) * rows).repeat_interleave(B)
+    sr_all += _rebase(world, B, int(rows), sr_all.dtype, x.device)
     return x_all, sr_all
 
 
@@ -113,3 +124,325 @@ class DataParallelStep:
         torch.add(b["loss"][:1], b["reg"][:1], out=b["total"])
         self._keep = (x_all, sr_all, de_all, st)
         return b["total"]
+
+
+# ======================================================================================================================
+# Row-sharded embedding table (SURVEY 8e "partitioning (north star)"): all-to-all lookup, sharded gradients
+# ======================================================================================================================
+def _backend(group=None):
+    return dist.get_backend(group) if dist.is_initialized() else None
+
+
+FORCE_COLLECTIVES = False          # tests: issue the collectives even in a one-rank group
+
+
+def _world(group=None):
+    return dist.get_world_size(group) if dist.is_initialized() else 1
+
+
+def _alone(group=None):
+    return not dist.is_initialized() or (dist.get_world_size(group) == 1 and not FORCE_COLLECTIVES)
+
+
+def _rank(group=None):
+    return dist.get_rank(group) if dist.is_initialized() else 0
+
+
+def all_to_all_rows(inp, out_splits, in_splits, group=None):
+    """Variable-size all-to-all along dim 0 (splits are host ints).  RCCL takes device tensors directly; gloo
+    (CPU rehearsal of the same code) is staged through host memory when the tensors live on a device."""
+    out = torch.empty((int(sum(out_splits)),) + tuple(inp.shape[1:]), dtype=inp.dtype, device=inp.device)
+    if _alone(group):
+        out.copy_(inp)
+        return out
+    if _backend(group) == "gloo" and inp.is_cuda:
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu().contiguous(), list(out_splits), list(in_splits), group=group)
+        out.copy_(o)
+        return out
+    dist.all_to_all_single(out, inp.contiguous(), list(out_splits), list(in_splits), group=group)
+    return out
+
+
+def reduce_scatter_flat(chunk_out, flat_in, group=None):
+    """chunk_out = sum over ranks of this rank's chunk of flat_in (flat_in.numel() == world * chunk_out.numel())."""
+    if _alone(group):
+        chunk_out.copy_(flat_in)
+    elif _backend(group) == "gloo":                      # gloo has no reduce_scatter: all_reduce + slice (tests only)
+        t = flat_in.cpu() if flat_in.is_cuda else flat_in.clone()
+        dist.all_reduce(t, group=group)
+        n = chunk_out.numel()
+        chunk_out.copy_(t[_rank(group) * n:(_rank(group) + 1) * n])
+    else:
+        dist.reduce_scatter_tensor(chunk_out, flat_in, op=dist.ReduceOp.SUM, group=group)
+    return chunk_out
+
+
+def all_gather_flat(flat_out, chunk_in, group=None):
+    if _alone(group):
+        flat_out.copy_(chunk_in)
+    elif _backend(group) == "gloo" and chunk_in.is_cuda:
+        o = torch.empty(flat_out.shape, dtype=flat_out.dtype)
+        dist.all_gather_into_tensor(o, chunk_in.cpu(), group=group)
+        flat_out.copy_(o)
+    else:
+        dist.all_gather_into_tensor(flat_out, chunk_in.contiguous(), group=group)
+    return flat_out
+
+
+def all_reduce_any(t, group=None):
+    if _alone(group):
+        return t
+    if _backend(group) == "gloo" and t.is_cuda:
+        c = t.cpu()
+        dist.all_reduce(c, group=group)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t, group=group)
+    return t
+
+
+class Route:
+    """Result of ShardRouter.route for one batch."""
+    __slots__ = ("slot", "n_unique", "send", "recv", "recv_rows")
+
+
+class ShardRouter:
+    """Index bookkeeping + collectives of the row-sharded table; pure tensor code, any backend / device.
+
+    Global table row r lives on rank r % P at local row r // P (interleaved, so the hot neighbours of the pad /
+    domain rows spread over the ranks).  route() deduplicates this rank's lookups (the pad row alone is ~37 % of
+    them), groups the unique rows by owner and exchanges the requests:
+        all_to_all #0  per-peer counts (P ints)            -> one host read of 2P ints (variable split sizes)
+        all_to_all #1  local row ids of the requested rows
+    fetch(): all_to_all #2 the requested rows come back in request order; push(): all_to_all #3 sends the
+    per-unique-row gradients to the owners in the same order (splits of #1 reversed)."""
+
+    def __init__(self, n_rows, group=None, world=None, rank=None):
+        self.group = group
+        self.P = _world(group) if world is None else int(world)      # world/rank overrides: index logic tests
+        self.p = _rank(group) if rank is None else int(rank)
+        self.n_rows = int(n_rows)
+        self.rows_per_rank = (self.n_rows + self.P - 1) // self.P
+        self._ws = None
+
+    def shard_of(self, table):
+        """this rank's rows of a full [R, E] table, zero-padded to rows_per_rank"""
+        part = table[self.p::self.P]
+        out = torch.zeros((self.rows_per_rank,) + tuple(table.shape[1:]), dtype=table.dtype, device=table.device)
+        out[:part.shape[0]].copy_(part)
+        return out
+
+    def unshard(self, shards, n_rows=None):
+        """inverse of shard_of over a list of every rank's shard (tests / checkpointing)"""
+        n_rows = self.n_rows if n_rows is None else n_rows
+        out = torch.empty((n_rows,) + tuple(shards[0].shape[1:]), dtype=shards[0].dtype, device=shards[0].device)
+        for q, s in enumerate(shards):
+            n = out[q::self.P].shape[0]
+            out[q::self.P] = s[:n]
+        return out
+
+    # ---- dedupe: (slot per lookup, unique local rows grouped by owner, owner boundaries) ---------------------------
+    def dedupe(self, bag):
+        """tensor-op statement of the routing index math (any device; the CPU/gloo rehearsal uses it)"""
+        P, Rp = self.P, self.rows_per_rank
+        g = bag.reshape(-1).to(torch.int64)
+        key = (g % P) * Rp + g // P                                  # owner-major: unique() output is grouped by owner
+        uniq, inv = torch.unique(key, return_inverse=True)
+        edges = torch.searchsorted(uniq, torch.arange(P + 1, device=uniq.device, dtype=torch.int64) * Rp)
+        return inv.to(torch.int32).reshape(bag.shape), (uniq % Rp).to(torch.int32), edges.to(torch.int32)
+
+    def dedupe_hip(self, x, offsets):
+        """the same on the device without a sort: aread_route_build (csrc/route.hip); bag = x + offsets"""
+        from . import _lib as L
+        L.require_device(x, offsets)
+        L.require(x, torch.int32, "x")
+        lib = L.lib()
+        if self._ws is None or self._ws.device != x.device:
+            self._ws = torch.zeros(int(lib.aread_route_ws_bytes(self.n_rows, self.P)), dtype=torch.uint8, device=x.device)
+        slot = torch.empty(x.shape, dtype=torch.int32, device=x.device)
+        uniq = torch.empty(x.numel(), dtype=torch.int32, device=x.device)
+        edges = torch.empty(self.P + 1, dtype=torch.int32, device=x.device)
+        L.check(lib.aread_route_build(L.ptr(x), x.shape[0], x.shape[1], L.ptr(offsets), self.n_rows, self.P, L.ptr(self._ws),
+                                      L.ptr(slot), L.ptr(uniq), L.ptr(edges), L.stream()))
+        return slot, uniq, edges
+
+    def _exchange(self, slot, uniq_rows, edges):
+        P = self.P
+        send_cnt = (edges[1:] - edges[:-1]).to(torch.int64)
+        both = torch.stack([send_cnt, all_to_all_rows(send_cnt, [1] * P, [1] * P, self.group)]).tolist()   # host read
+        r = Route()
+        r.send, r.recv = [int(v) for v in both[0]], [int(v) for v in both[1]]
+        r.n_unique = sum(r.send)
+        r.slot = slot                                                # lookup -> slot in this rank's unique-row buffer
+        r.recv_rows = all_to_all_rows(uniq_rows[:r.n_unique], r.recv, r.send, self.group)        # local rows asked of me
+        return r
+
+    def route(self, bag):
+        return self._exchange(*self.dedupe(bag))
+
+    def route_hip(self, x, offsets):
+        return self._exchange(*self.dedupe_hip(x, offsets))
+
+    def fetch(self, route, rows):
+        """rows [sum(recv), E] (this rank's rows for route.recv_rows) -> [n_unique, E] in slot order"""
+        return all_to_all_rows(rows, route.send, route.recv, self.group)
+
+    def push(self, route, g_unique):
+        """g_unique [n_unique, E] -> [sum(recv), E] aligned with route.recv_rows"""
+        return all_to_all_rows(g_unique, route.recv, route.send, self.group)
+
+
+class ShardedTableStep:
+    """Weak-scaling training step with the embedding table row-sharded over the ranks and ZeRO-1 style dense
+    parameters (SURVEY 8e north-star partitioning; BASELINE config 4).
+
+      lookup    : ids -> ShardRouter.route (dedupe, all_to_all ids) -> owners gather their rows (aread_embed_fwd,
+                  one column) -> all_to_all rows -> aread_embed_fwd over the received unique rows (slot ids, zero
+                  offsets, the row plan) -> pooled embedding e, bit-identical to the unsharded gather
+      dense     : rank-local forward / bagging BCE / backward (libaread_hip), BatchNorm per replica
+      table grad: aread_embed_bwd into the unique-row buffer -> all_to_all to the owners -> aread_embed_bwd (one
+                  column) into the shard gradient, which the shard-local L2 pass initialised with 2*l2*W_shard
+      dense grad: reduce_scatter of the flat gradient (equal chunks), dense L2 on the owned chunk; adam_step()
+                  updates shard + owned chunk and all_gathers the dense parameters.
+    The loss convention is the DataParallelStep's: objective = sum over ranks of the rank losses + reg (once).
+    Two host reads per step (unique count, split sizes) -- the usual price of a variable-size all-to-all."""
+
+    def __init__(self, model, B, group=None):
+        import ctypes as C
+        from . import _lib as L
+        self._C, self._L = C, L
+        self.model, self.group = model, group
+        self.P, self.p = _world(group), _rank(group)
+        emb = model.embedding
+        table = emb.embedding_dict.weight.data
+        dev = table.device
+        self.router = ShardRouter(table.shape[0], group)
+        self.shard = torch.nn.Parameter(self.router.shard_of(table))
+        self.gshard = torch.empty_like(self.shard.data)
+        self.bufs = model.make_step_buffers(B, multi_domain=True, with_table_grad=False)
+        n = model.dense.numel()
+        self.chunk = (n + self.P - 1) // self.P
+        self.gpad = torch.zeros(self.chunk * self.P, dtype=torch.float32, device=dev)
+        self.dense_pad = torch.zeros(self.chunk * self.P, dtype=torch.float32, device=dev)
+        self.dense_pad[:n].copy_(model.dense.data)
+        self.coef_pad = torch.zeros(self.chunk * self.P, dtype=torch.float32, device=dev)
+        self.coef_pad[:n].copy_(model._l2_coef(dev))
+        lo = self.p * self.chunk
+        self.dense_chunk = torch.nn.Parameter(self.dense_pad[lo:lo + self.chunk].clone())
+        self.gchunk = torch.zeros(self.chunk, dtype=torch.float32, device=dev)
+        self.reg = torch.zeros(257, dtype=torch.float32, device=dev)
+        self.total = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._zero17 = torch.zeros(emb.offsets.shape[0], dtype=torch.int32, device=dev)
+        self._zero1 = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._ws = {}
+        self._opt = None
+        self._side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+
+    # ---- C-ABI helpers -------------------------------------------------------------------------------------------
+    def _bwd_ws(self, tag, B, f_in):
+        L, E = self._L, self.model.embedding.embed_dim
+        need = int(L.lib().aread_embed_bwd_ws_bytes(B, f_in, E))
+        if need < 0:
+            raise RuntimeError("aread_embed_bwd_ws_bytes failed")
+        ws = self._ws.get(tag)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(max(need, int(need * 1.25)), dtype=torch.uint8, device=self.shard.device)
+            self._ws[tag] = ws
+        return ws
+
+    def _gather_owned(self, local_rows):
+        """rows of this rank's shard for the requests of every peer: [n, E]"""
+        L, emb = self._L, self.model.embedding
+        n = int(local_rows.shape[0])
+        out = torch.empty((n, emb.embed_dim), dtype=torch.float32, device=self.shard.device)
+        if n:
+            L.check(L.lib().aread_embed_fwd(L.ptr(local_rows), n, 1, L.ptr(self._zero1), L.ptr(self.shard.data),
+                                            self.shard.shape[0], emb.embed_dim, 1, 0, 1, 0, None, n, L.ptr(out), None,
+                                            L.stream()))
+        return out
+
+    def lookup(self, x, plan):
+        """-> (route, unique rows); fills bufs['e'] (plan order)"""
+        L, emb, b = self._L, self.model.embedding, self.bufs
+        route = self.router.route_hip(x, emb._offsets_dev(x.device))
+        urows = self.router.fetch(route, self._gather_owned(route.recv_rows))
+        L.check(L.lib().aread_embed_fwd(L.ptr(route.slot), x.shape[0], x.shape[1], L.ptr(self._zero17), L.ptr(urows),
+                                        urows.shape[0], emb.embed_dim, emb.one_hot_field_num, emb.multi_hot_field_num,
+                                        emb.seq_maxlen, emb._pool, L.ptr(plan.row_sample), plan.max_rows, L.ptr(b["e"]),
+                                        None, L.stream()))
+        return route, urows
+
+    def presort(self, x, route, plan):
+        """index sorts of both segmented reductions of table_grad (they depend only on the ids): side stream"""
+        L, emb = self._L, self.model.embedding
+        lib = L.lib()
+        B, f_in = x.shape
+        n = int(route.recv_rows.shape[0])
+        ws_u, ws_o = self._bwd_ws("u", B, f_in), self._bwd_ws("o", max(n, 1), 1)
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            L.check(lib.aread_embed_bwd_sort(L.ptr(route.slot), B, f_in, L.ptr(self._zero17), route.n_unique, emb.embed_dim,
+                                             emb.one_hot_field_num, emb.multi_hot_field_num, emb.seq_maxlen, emb._pool,
+                                             L.ptr(plan.sample_row), L.ptr(ws_u), L.stream()))
+            if n:
+                L.check(lib.aread_embed_bwd_sort(L.ptr(route.recv_rows), n, 1, L.ptr(self._zero1), self.shard.shape[0],
+                                                 emb.embed_dim, 1, 0, 1, 0, None, L.ptr(ws_o), L.stream()))
+
+    def table_grad(self, x, route, plan):
+        """bufs['de'] -> self.gshard (+= on top of the shard's L2 gradient); presort() must have run"""
+        L, emb, b = self._L, self.model.embedding, self.bufs
+        lib = L.lib()
+        B, f_in = x.shape
+        seq = emb.seq_maxlen if emb._pool != 0 else 1
+        g_unique = torch.zeros((route.n_unique, emb.embed_dim), dtype=torch.float32, device=x.device)
+        torch.cuda.current_stream().wait_stream(self._side)
+        L.check(lib.aread_embed_bwd_reduce(B, f_in, emb.embed_dim, seq, L.ptr(b["de"]), L.ptr(g_unique),
+                                           L.ptr(self._bwd_ws("u", B, f_in)), L.stream()))
+        g_recv = self.router.push(route, g_unique)
+        n = int(g_recv.shape[0])
+        if n:
+            L.check(lib.aread_embed_bwd_reduce(n, 1, emb.embed_dim, 1, L.ptr(g_recv), L.ptr(self.gshard),
+                                               L.ptr(self._bwd_ws("o", n, 1)), L.stream()))
+
+    def step(self, x, y, masks_dev):
+        from .plan import RowPlan
+        L, m, b = self._L, self.model, self.bufs
+        lib = L.lib()
+        plan = RowPlan(x, m.domain_idx, m.n_domain)
+        route, urows = self.lookup(x, plan)
+        self.presort(x, route, plan)
+        st = m.step_local(x, y, b, masks_dev=masks_dev, with_dense_l2=False, presort=False, plan=plan, e_ready=True,
+                          l2_target=(self.shard.data, self.gshard))
+        self.table_grad(x, route, plan)
+        m.step_finish(b)                                               # dense gradients of the local batch complete
+        n = m.dense.numel()
+        self.gpad[:n].copy_(b["gdense"])
+        reduce_scatter_flat(self.gchunk, self.gpad, self.group)
+        lo = self.p * self.chunk
+        self.reg.copy_(b["reg"])                                       # table L2 of this shard
+        L.check(lib.aread_l2_dense(L.ptr(self.dense_chunk.data), L.ptr(self.coef_pad[lo:lo + self.chunk]), self.chunk,
+                                   L.ptr(self.gchunk), L.ptr(self.reg), 1, L.stream()))
+        reg = all_reduce_any(self.reg[:1].clone(), self.group)         # reg = sum over shards / chunks
+        torch.add(b["loss"][:1], reg, out=self.total)
+        self._keep = (route, urows, st, plan)
+        return self.total
+
+    # ---- ZeRO-1 optimizer step (outside the fwd+bwd metric) ---------------------------------------------------------
+    def adam_step(self, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-8):
+        """Adam (run.py:830-831 hyper-parameters) on the owned table shard and dense chunk, then all_gather of the
+        dense parameters into every replica's model.dense."""
+        if self._opt is None:
+            self._opt = torch.optim.Adam([self.shard, self.dense_chunk], lr=lr, betas=betas, eps=eps,
+                                         weight_decay=weight_decay)
+        self.shard.grad, self.dense_chunk.grad = self.gshard, self.gchunk
+        self._opt.step()
+        all_gather_flat(self.dense_pad, self.dense_chunk.data, self.group)
+        self.model.dense.data.copy_(self.dense_pad[:self.model.dense.numel()])
+
+    def full_table(self):
+        """gathers the shards back into a [R, E] table (checkpointing / tests)"""
+        flat = torch.empty((self.P,) + tuple(self.shard.shape), dtype=torch.float32, device=self.shard.device)
+        all_gather_flat(flat.view(-1), self.shard.data.reshape(-1), self.group)
+        return self.router.unshard(list(flat))

@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3"],
                     help="GEMM arithmetic of the expert/tower forward+dgrad: exact fp32 MFMA or split-bf16 (3 products)")
     ap.add_argument("--force-dp", action="store_true", help="use the multi-GPU code path even with one rank (testing)")
+    ap.add_argument("--table", default="auto", choices=["auto", "replicated", "sharded"],
+                    help="multi-GPU embedding table: replicated (all_gather of ids/dE) or row-sharded (all_to_all lookup, "
+                         "reduce_scatter of the dense gradient); auto times both briefly and keeps the faster")
     return ap.parse_args()
 
 
@@ -59,6 +62,10 @@ def log(msg):
 
 def main():
     args = parse()
+    # stdout carries exactly one JSON line: everything else (RCCL prints a version banner on fd 1) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -95,14 +102,20 @@ def main():
     ys = torch.empty_like(batches[0][1])
     dp_state = {}
     if use_dp:
-        from aread_amd.dist import DataParallelStep
-        dp = DataParallelStep(model, B)
+        import aread_amd.dist as D
+        D.FORCE_COLLECTIVES = world == 1              # --force-dp: still go through RCCL
+        dp = D.DataParallelStep(model, B, force_overlap=world == 1)
         bufs = dp.bufs
+        variants = {"replicated": (lambda: dp.step(xs, ys, masks_dev), bufs["total"])}
+        if args.table != "replicated":
+            sh = D.ShardedTableStep(model, B)
+            variants["sharded"] = (lambda: sh.step(xs, ys, masks_dev), sh.total)
+        dp_state["variant"] = "sharded" if args.table == "sharded" else "replicated"
 
         args.no_graph = True                          # the multi-GPU step is eager: collectives interleave with compute
 
         def step():
-            dp.step(xs, ys, masks_dev)
+            variants[dp_state["variant"]][0]()
 
         def after():
             pass
@@ -171,6 +184,20 @@ def main():
         log(f"launch mode: graph {t_graph * 1e3:.3f} ms/step, eager multi-stream {t_eager * 1e3:.3f} ms/step")
         graph = captured if t_graph < t_eager else None
 
+    # multi-GPU table variant: time both briefly (max over ranks), keep the faster
+    if use_dp and args.table == "auto":
+        times = {}
+        for name in variants:
+            dp_state["variant"] = name
+            quick(3)
+            dist.barrier()
+            tt = torch.tensor([quick()], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            times[name] = float(tt[0])
+        dp_state["variant"] = min(times, key=times.get)
+        dp_state["times_ms"] = {k: round(v * 1e3, 4) for k, v in times.items()}
+        log(f"table variant: {dp_state['times_ms']} -> {dp_state['variant']}")
+
     for i in range(args.warmup):
         run_one(i)
     torch.cuda.synchronize()
@@ -189,7 +216,7 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
-    loss = float(bufs["total"])
+    loss = float(variants[dp_state["variant"]][1]) if use_dp else float(bufs["total"])
     log(f"timed region done: {dt / args.steps * 1e3:.3f} ms/step")
     ms_per_step = dt / args.steps * 1e3
     value = world * B * args.steps / dt
@@ -214,8 +241,12 @@ def main():
                    "batch_per_gpu": B, "global_batch": B * world, "domain_dist": args.domain_dist,
                    "dropout": args.dropout, "mask_active_frac": 0.7, "optimizer_in_timed_region": False,
                    "dense_table_l2_in_timed_region": True, "launch": "hipGraph replay" if graph is not None else "eager, fork-join side streams",
-                   "parallelism": f"dp{world}" + (": replicated table, all_gather(ids,dE)+all_reduce(dense grads) over RCCL"
-                                                   if use_dp else "")},
+                   "parallelism": f"dp{world}" + ("" if not use_dp else
+                                                   ": replicated table, all_gather(ids,dE)+all_reduce(dense grads) over RCCL"
+                                                   if dp_state["variant"] == "replicated" else
+                                                   ": row-sharded table (r % P), all_to_all(ids,rows,row grads)+"
+                                                   "reduce_scatter(dense grads) over RCCL, 2 host reads/step"),
+                   **({"table_variants_ms": dp_state["times_ms"]} if "times_ms" in dp_state else {})},
         "roofline": roofline, "gemm_roofline": gemm, "l2_table_roofline": l2pass, "gather_roofline": gather,
         "gather_roofline_b65536": gather_big,
         "loss": round(loss, 6),
@@ -223,7 +254,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(O, spec, P, masks, batches, args)
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dp:
         dist.destroy_process_group()
 

@@ -103,6 +103,21 @@ int aread_embed_bwd_reduce(int64_t B, int f_in, int E, int seq_len, const float*
                            void* ws, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Lookup routing for a row-sharded table (multi-GPU extension; no counterpart in the single-device
+ * reference -- it sits between FeaturesEmbedding's index bag, layer.py:165-166, and the gather).
+ * Global row g = x + offsets lives on rank g % n_ranks at local row g / n_ranks.  Deduplicates the batch's rows
+ * and groups them by owner, without sorting (direct-addressed flag array over the key space):
+ *   slot_out      [B*f_in]  lookup -> index of its row in the unique list
+ *   uniq_rows_out [<= B*f_in] LOCAL row of every unique row, ordered by (owner, local row)
+ *   edges_out     [n_ranks+1] unique rows of owner q are uniq_rows_out[edges[q] .. edges[q+1]); edges[n_ranks] = count
+ * ws: aread_route_ws_bytes() bytes, ZERO-FILLED by the caller before the first call; every call leaves it zeroed
+ * where it matters, so the same buffer is reused step after step.  Integer work, bit-exact. */
+int64_t aread_route_ws_bytes(int64_t n_table_rows, int n_ranks);
+int aread_route_build(const int32_t* x, int64_t B, int f_in, const int32_t* offsets, int64_t n_table_rows,
+                      int n_ranks, void* ws, int32_t* slot_out, int32_t* uniq_rows_out, int32_t* edges_out,
+                      void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Dense L2 term of the embedding table.  Replaces the table part of
  * BaseModel.get_regularization_loss (model/layer.py:96-112, registered at layer.py:31):
  *   loss += l2 * sum(w^2);   grad = grad_scale * 2*l2*w   (written, not accumulated)

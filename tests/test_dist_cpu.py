@@ -92,3 +92,83 @@ def test_gather_and_reduce_world2():
     assert sorted(r[0] for r in res) == list(range(world))
     assert all(r[1] for r in res), res
     assert all(r[2] for r in res), res
+
+
+# ---- row-sharded table: ShardRouter (all-to-all lookup / gradient push), reduce-scatter helpers ------------------------
+def _shard_data(spec, rank, B, n_rows, E):
+    rng = np.random.default_rng(500 + rank)
+    bag = rng.integers(0, n_rows, (B, 17)).astype(np.int32)
+    bag[rng.random((B, 17)) < 0.4] = n_rows - 3               # a hot (pad-like) row, deduplicated before sending
+    g_lookup = rng.standard_normal((B * 17, E)).astype(np.float32)
+    return bag, g_lookup
+
+
+def _shard_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import aread_amd.dist as D
+        n_rows, E, B = 1001, 8, 64                               # 1001 rows: the shards are ragged (334/334/333)
+        table = torch.from_numpy(np.random.default_rng(7).standard_normal((n_rows, E)).astype(np.float32))
+        router = D.ShardRouter(n_rows)
+        shard = router.shard_of(table)
+        bag, g_lookup = _shard_data(None, rank, B, n_rows, E)
+        route = router.route(torch.from_numpy(bag))
+        urows = router.fetch(route, shard[route.recv_rows.long()])
+        ok_fwd = torch.equal(urows[route.slot.long()], table[torch.from_numpy(bag).long()])
+        ok_dedupe = route.n_unique == len(np.unique(bag)) and sum(route.send) == route.n_unique
+        g_unique = torch.zeros(route.n_unique, E, dtype=torch.float64).index_add_(
+            0, route.slot.reshape(-1).long(), torch.from_numpy(g_lookup).double())
+        g_recv = router.push(route, g_unique)
+        gshard = torch.zeros(shard.shape, dtype=torch.float64).index_add_(0, route.recv_rows.long(), g_recv)
+        shards = [torch.empty_like(gshard) for _ in range(world)]
+        dist.all_gather(shards, gshard)
+        got = router.unshard(shards).numpy()
+        exp = np.zeros((n_rows, E))
+        for r in range(world):
+            br, gr = _shard_data(None, r, B, n_rows, E)
+            np.add.at(exp, br.reshape(-1), gr.astype(np.float64))
+        ok_bwd = np.allclose(got, exp, rtol=1e-12, atol=1e-12)
+        # shard_of / unshard round trip over every rank's shard
+        tabs = [torch.empty_like(shard) for _ in range(world)]
+        dist.all_gather(tabs, shard)
+        ok_rt = torch.equal(router.unshard(tabs), table)
+        # flat reduce-scatter / all-gather helpers
+        chunk = 5
+        flat = torch.arange(world * chunk, dtype=torch.float32) * (rank + 1)
+        mine = D.reduce_scatter_flat(torch.empty(chunk), flat)
+        tot = sum(range(1, world + 1))
+        ok_rs = torch.equal(mine, torch.arange(rank * chunk, (rank + 1) * chunk, dtype=torch.float32) * tot)
+        back = D.all_gather_flat(torch.empty(world * chunk), mine)
+        ok_ag = torch.equal(back, torch.arange(world * chunk, dtype=torch.float32) * tot)
+        q.put((rank, bool(ok_fwd), bool(ok_dedupe), bool(ok_bwd), bool(ok_rt), bool(ok_rs), bool(ok_ag)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("world", [2, 3])
+def test_shard_router(world):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=100) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=30)
+    assert sorted(r[0] for r in res) == list(range(world))
+    assert all(all(r[1:]) for r in res), res
+
+
+def test_shard_router_single_process():
+    """no process group: the router degenerates to dedupe + identity exchange"""
+    import aread_amd.dist as D
+    router = D.ShardRouter(50)
+    bag = torch.tensor([[3, 3, 49], [0, 3, 7]], dtype=torch.int32)
+    route = router.route(bag)
+    assert route.n_unique == 4 and route.send == [4] and route.recv == [4]
+    assert route.recv_rows.tolist() == [0, 3, 7, 49]
+    assert route.slot.tolist() == [[1, 1, 3], [0, 1, 2]]
