@@ -562,14 +562,16 @@ class AREAD(HempMixin, nn.Module):
         return self._streams[key]
 
     def step_local(self, x, y, bufs, masks_dev=None, domain_i=None, seg_weight=None, with_reg=True,
-                   with_dense_l2=True, want_gates=False, presort=True, plan=None, e_ready=False, l2_target=None):
+                   with_dense_l2=True, want_gates=False, presort=True, plan=None, e_ready=False, l2_target=None,
+                   table_pass=True):
         """Rank-local part of the step: row plan, gather, dense forward + bagging BCE + backward on the current
         stream; concurrently on a side stream (fork-join, capturable): the table L2 pass
         (bufs['gtable'] = 2*l2*W, bufs['reg'] = l2 terms) and, with presort, the index sort of the embedding
         backward.  Leaves bufs['de'] (gradient w.r.t. the pooled embedding, plan order) for step_scatter.
         No host sync, no allocation besides the row plan.
         e_ready / l2_target=(rows, grad): row-sharded table -- bufs['e'] is already filled and the L2 pass runs over
-        this rank's shard instead of the full table."""
+        this rank's shard instead of the full table.  table_pass=False: no dense table gradient at all (the fused
+        optimizer folds the L2 term into its own pass, optim.FusedAdam)."""
         lib = L.lib()
         n_seg = bufs["n_seg"]
         table, gtable = (self.embedding.embedding_dict.weight, bufs["gtable"]) if l2_target is None else l2_target
@@ -582,7 +584,9 @@ class AREAD(HempMixin, nn.Module):
         self.embedding._ws_for(x)                      # allocate on the main stream's pool before forking
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            if with_reg:
+            if not table_pass:
+                bufs["reg"].zero_()
+            elif with_reg:
                 L.check(lib.aread_l2_table(L.ptr(table), table.numel(), self.l2_reg_embedding, 1.0, L.ptr(gtable),
                                            L.ptr(part), L.stream()))
                 L.check(lib.aread_l2_finish(L.ptr(part), part.numel(), self.l2_reg_embedding, L.ptr(bufs["reg"]), 0,

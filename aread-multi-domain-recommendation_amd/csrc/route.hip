@@ -11,27 +11,7 @@
 //   k_route_slot   slot[i] = slot_of_key[key_i]; flags are cleared again (the workspace stays zero between calls)
 // Five short launches instead of a sort + unique; everything is integer work, bit-exact by construction.
 #include "common.h"
-
-#define RT_THREADS 256
-#define RT_ITEMS 16
-#define RT_BLOCK (RT_THREADS * RT_ITEMS)
-
-struct RouteWs {
-    int64_t n_keys, n_blk;
-    int64_t off_flags, off_slotmap, off_bsum, total;
-};
-static inline int64_t rt_align(int64_t x) { return (x + 255) & ~(int64_t)255; }
-static int route_layout(int64_t n_keys, RouteWs* L) {
-    if (n_keys <= 0 || n_keys >= (1ll << 31)) return -1;
-    L->n_keys = n_keys;
-    L->n_blk = (n_keys + RT_BLOCK - 1) / RT_BLOCK;
-    int64_t o = 0;
-    L->off_flags = o;   o = rt_align(o + L->n_blk * RT_BLOCK);          // uint8, padded to whole blocks
-    L->off_slotmap = o; o = rt_align(o + n_keys * 4);
-    L->off_bsum = o;    o = rt_align(o + (L->n_blk + 1) * 4);
-    L->total = o;
-    return 0;
-}
+#include "route.h"
 
 __device__ __forceinline__ int route_key(int g, int n_rows, int P, int Rp) {
     g = g < 0 ? 0 : (g >= n_rows ? n_rows - 1 : g);                      // ids are not validated upstream: never store OOB
@@ -133,13 +113,13 @@ __global__ __launch_bounds__(RT_THREADS) void k_route_assign(const uint8_t* __re
 __global__ __launch_bounds__(256) void k_route_slot(const int32_t* __restrict__ x, const int32_t* __restrict__ offsets,
                                                     int64_t n, int f_in, int n_rows, int P, int Rp,
                                                     const int32_t* __restrict__ slotmap, uint8_t* __restrict__ flags,
-                                                    int32_t* __restrict__ slot) {
+                                                    int32_t* __restrict__ slot, int keep_flags) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int j = (int)(i % f_in);
     const int key = route_key(x[i] + offsets[j], n_rows, P, Rp);
     slot[i] = slotmap[key];
-    flags[key] = 0;                                                      // every set flag belongs to some lookup
+    if (!keep_flags) flags[key] = 0;                                     // every set flag belongs to some lookup
 }
 
 extern "C" int64_t aread_route_ws_bytes(int64_t n_table_rows, int n_ranks) {
@@ -152,7 +132,7 @@ extern "C" int64_t aread_route_ws_bytes(int64_t n_table_rows, int n_ranks) {
 
 extern "C" int aread_route_build(const int32_t* x, int64_t B, int f_in, const int32_t* offsets, int64_t n_table_rows,
                                  int n_ranks, void* ws, int32_t* slot_out, int32_t* uniq_rows_out, int32_t* edges_out,
-                                 void* stream) {
+                                 int keep_flags, void* stream) {
     AR_CHECK_ARG(x && offsets && ws && slot_out && uniq_rows_out && edges_out, "aread_route_build: null pointer");
     AR_CHECK_ARG(B > 0 && f_in > 0 && n_ranks > 0 && n_ranks <= 1024, "aread_route_build: bad sizes");
     AR_CHECK_ARG(n_table_rows > 0 && n_table_rows < (1ll << 31), "aread_route_build: bad table size");
@@ -179,7 +159,7 @@ extern "C" int aread_route_build(const int32_t* x, int64_t B, int f_in, const in
                        n_ranks, (int)Rp, slotmap, uniq_rows_out, edges_out);
     AR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_route_slot, dim3(g_n), dim3(256), 0, st, x, offsets, n, f_in, (int)n_table_rows, n_ranks, (int)Rp,
-                       slotmap, flags, slot_out);
+                       slotmap, flags, slot_out, keep_flags);
     AR_LAUNCH_CHECK();
     return AREAD_OK;
 }

@@ -264,7 +264,7 @@ class ShardRouter:
         uniq = torch.empty(x.numel(), dtype=torch.int32, device=x.device)
         edges = torch.empty(self.P + 1, dtype=torch.int32, device=x.device)
         L.check(lib.aread_route_build(L.ptr(x), x.shape[0], x.shape[1], L.ptr(offsets), self.n_rows, self.P, L.ptr(self._ws),
-                                      L.ptr(slot), L.ptr(uniq), L.ptr(edges), L.stream()))
+                                      L.ptr(slot), L.ptr(uniq), L.ptr(edges), 0, L.stream()))
         return slot, uniq, edges
 
     def _exchange(self, slot, uniq_rows, edges):

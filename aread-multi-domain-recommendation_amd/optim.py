@@ -1,0 +1,126 @@
+"""Fused training step with the optimizer inside: forward + bagging BCE + L2 + backward + Adam,
+no dense 178 MB table gradient and no per-tensor optimizer launches.
+
+Same update as the reference's step closure (run.py:668-682) followed by
+torch.optim.Adam(model.parameters(), lr, betas=(0.9, 0.99), eps=1e-8, weight_decay=wd) (run.py:830-831):
+  * embedding table: g = 2*l2*W + scatter(dE) is never materialised -- aread_route_build (one rank) deduplicates the
+    batch's rows, aread_embed_bwd reduces dE into one gradient row per looked-up table row, aread_adam_table_l2
+    streams W, m, v once (6 x 4 B per element instead of 9 x) and also yields sum(W^2) for the loss value;
+  * dense tensors: aread_adam_step over the flat buffer; tensors the reference's autograd would leave at grad=None
+    (towers no mask reaches) are skipped exactly as torch.optim.Adam skips them, with per-tensor step counts."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .plan import RowPlan
+
+
+class AdamCfg(C.Structure):
+    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("weight_decay", C.c_float), ("step", C.c_int32)]
+
+
+class FusedAdam:
+    def __init__(self, model, B, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-8):
+        self.model = model
+        self.hyper = (float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay))
+        table = model.embedding.embedding_dict.weight.data
+        dev = table.device
+        lib = L.lib()
+        self.bufs = model.make_step_buffers(B, multi_domain=True, with_table_grad=False)
+        self.m_table, self.v_table = torch.zeros_like(table), torch.zeros_like(table)
+        self.m_dense, self.v_dense = torch.zeros_like(model.dense), torch.zeros_like(model.dense)
+        self.t_table = 0
+        self.t_dense = np.zeros(len(model._ptensors), dtype=np.int64)          # torch keeps one step count per tensor
+        f_in = model.embedding.offsets.shape[0]
+        self.cap = B * f_in                                                     # unique rows <= lookups
+        self.route_ws = torch.zeros(int(lib.aread_route_ws_bytes(table.shape[0], 1)), dtype=torch.uint8, device=dev)
+        self.slot = torch.empty((B, f_in), dtype=torch.int32, device=dev)
+        self.uniq = torch.empty(self.cap, dtype=torch.int32, device=dev)
+        self.edges = torch.empty(2, dtype=torch.int32, device=dev)
+        self.g_rows = torch.empty((self.cap, table.shape[1]), dtype=torch.float32, device=dev)
+        self.zero_off = torch.zeros(f_in, dtype=torch.int32, device=dev)
+        self.sort_ws = torch.empty(int(lib.aread_embed_bwd_ws_bytes(B, f_in, table.shape[1])), dtype=torch.uint8, device=dev)
+        self.part = torch.empty(lib.aread_l2_partials(), dtype=torch.float32, device=dev)
+        self.total = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._side = torch.cuda.Stream(device=dev)
+        self._masks_key, self._present = None, None
+        self._active = {}
+
+    # ---- which dense tensors get a gradient (host logic, cached per mask set) -----------------------------------------
+    def _present_for(self, masks):
+        key = id(masks)
+        if key != self._masks_key:
+            m = self.model
+            self._present = np.array([a or b for a, b in zip(m._presence(0, masks), m._reg_present)], dtype=bool)
+            self._masks_key = key
+        return self._present
+
+    def _active_mask(self, sel):
+        """uint8 [n_dense]: 1 on the elements of the selected tensors"""
+        key = sel.tobytes()
+        if key not in self._active:
+            m = self.model
+            a = np.zeros(m.dense.numel(), dtype=np.uint8)
+            for on, (name, kind, off, shape, l2) in zip(sel, m._ptensors):
+                if on:
+                    a[off:off + (int(np.prod(shape)) if shape else 1)] = 1
+            self._active[key] = torch.from_numpy(a).to(m.dense.device)
+        return self._active[key]
+
+    def _cfg(self, step):
+        c = AdamCfg()
+        c.lr, c.beta1, c.beta2, c.eps, c.weight_decay = self.hyper
+        c.step = int(step)
+        return c
+
+    # ---- one training step ---------------------------------------------------------------------------------------------
+    def step(self, x, y, masks_dev=None, masks=None):
+        """forward + loss + backward + Adam on every parameter; returns the device scalar loss (pre-update weights).
+        masks: the per-domain mask list that masks_dev packs (default: model.domain_mask)."""
+        m, b = self.model, self.bufs
+        lib = L.lib()
+        emb = m.embedding
+        table = emb.embedding_dict.weight.data
+        masks = m.domain_mask if masks is None else masks
+        if masks_dev is None:
+            masks_dev = m._masks_dev(masks, x.device)
+        Bn, f_in = x.shape
+        E = emb.embed_dim
+        main, side = torch.cuda.current_stream(), self._side
+        plan = RowPlan(x, m.domain_idx, m.n_domain)
+        # side stream: dedupe of the batch's rows + index sort of the row-gradient reduction (ids only)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            L.check(lib.aread_route_build(L.ptr(x), Bn, f_in, L.ptr(emb._offsets_dev(x.device)), table.shape[0], 1,
+                                          L.ptr(self.route_ws), L.ptr(self.slot), L.ptr(self.uniq), L.ptr(self.edges), 1,
+                                          L.stream()))
+            L.check(lib.aread_embed_bwd_sort(L.ptr(self.slot), Bn, f_in, L.ptr(self.zero_off), self.cap, E,
+                                             emb.one_hot_field_num, emb.multi_hot_field_num, emb.seq_maxlen, emb._pool,
+                                             L.ptr(plan.sample_row), L.ptr(self.sort_ws), L.stream()))
+            self.g_rows.zero_()
+        m.step_local(x, y, b, masks_dev=masks_dev, with_dense_l2=False, presort=False, plan=plan, table_pass=False)
+        main.wait_stream(side)
+        seq = emb.seq_maxlen if emb._pool != 0 else 1
+        L.check(lib.aread_embed_bwd_reduce(Bn, f_in, E, seq, L.ptr(b["de"]), L.ptr(self.g_rows), L.ptr(self.sort_ws),
+                                           L.stream()))
+        self.t_table += 1
+        cfg = self._cfg(self.t_table)
+        L.check(lib.aread_adam_table_l2(L.ptr(table), L.ptr(self.m_table), L.ptr(self.v_table), table.shape[0], E,
+                                        L.ptr(self.route_ws), L.ptr(self.uniq), L.ptr(self.edges), L.ptr(self.g_rows),
+                                        m.l2_reg_embedding, C.byref(cfg), L.ptr(self.part), L.stream()))
+        L.check(lib.aread_l2_finish(L.ptr(self.part), self.part.numel(), m.l2_reg_embedding, L.ptr(b["reg"]), 0, L.stream()))
+        m.step_finish(b)                                    # dense gradients complete
+        m.add_dense_l2(b)                                   # reg += dense terms, gdense += 2*coef*w
+        torch.add(b["loss"][:1], b["reg"][:1], out=self.total)
+        present = self._present_for(masks)
+        self.t_dense[present] += 1
+        for t in np.unique(self.t_dense[present]):
+            sel = present & (self.t_dense == t)
+            act = None if sel.all() else self._active_mask(sel)
+            cfg = self._cfg(t)
+            L.check(lib.aread_adam_step(L.ptr(m.dense), L.ptr(b["gdense"]), L.ptr(self.m_dense), L.ptr(self.v_dense),
+                                        m.dense.numel(), L.ptr(act), C.byref(cfg), L.stream()))
+        return self.total

@@ -251,6 +251,9 @@ def main():
         "gather_roofline_b65536": gather_big,
         "loss": round(loss, 6),
     }
+    if world == 1 and not use_dp:
+        # beyond the metric: the same step WITH the optimizer, fused (modifies the parameters: runs last)
+        out["train_step_with_fused_adam"] = measure_fused_adam(model, batches, masks_dev, B, L)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(O, spec, P, masks, batches, args)
     if rank == 0:
@@ -330,6 +333,35 @@ def measure_l2_kernel(model, bufs, L):
     return {"kernel": "k_l2_table", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic("k_l2_table"), "algorithmic_bytes_per_launch": alg,
             "avg_launch_us": round(t * 1e6, 2)}
+
+
+def measure_fused_adam(model, batches, masks_dev, B, L, steps=30):
+    """forward + loss + backward + Adam on all 45 M parameters per step (aread_amd.FusedAdam), and the table-optimizer
+    kernel alone: 6 x 4 B per table element (w, m, v read and written), L2 term folded in."""
+    import ctypes as C
+    import aread_amd
+    opt = aread_amd.FusedAdam(model, B)
+    for i in range(3):
+        opt.step(batches[i % len(batches)][0], batches[i % len(batches)][1], masks_dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        opt.step(batches[i % len(batches)][0], batches[i % len(batches)][1], masks_dev)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    table = model.embedding.embedding_dict.weight.data
+    cfg = opt._cfg(100)
+    fn = lambda: L.check(L.lib().aread_adam_table_l2(L.ptr(table), L.ptr(opt.m_table), L.ptr(opt.v_table), table.shape[0],
+                                                     table.shape[1], None, None, None, None, model.l2_reg_embedding,
+                                                     C.byref(cfg), L.ptr(opt.part), L.stream()))
+    t = _time_kernel(fn, iters=20)
+    alg = 6.0 * table.numel() * 4
+    return {"ms_per_step": round(dt * 1e3, 4), "samples_per_s": round(B / dt, 1), "optimizer": "Adam(lr 1e-3, betas (0.9,0.99), "
+            "eps 1e-8, coupled weight_decay 1e-8) on table + dense, L2 folded into the table pass, no dense table gradient",
+            "loss_after": round(float(opt.total), 6),
+            "k_adam_table": {"bound": "hbm", "achieved": round(alg / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(alg / t / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": alg,
+                             "avg_launch_us": round(t * 1e6, 2)}}
 
 
 def measure_gather_kernel(model, xs, bufs, L):

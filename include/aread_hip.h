@@ -111,11 +111,13 @@ int aread_embed_bwd_reduce(int64_t B, int f_in, int E, int seq_len, const float*
  *   uniq_rows_out [<= B*f_in] LOCAL row of every unique row, ordered by (owner, local row)
  *   edges_out     [n_ranks+1] unique rows of owner q are uniq_rows_out[edges[q] .. edges[q+1]); edges[n_ranks] = count
  * ws: aread_route_ws_bytes() bytes, ZERO-FILLED by the caller before the first call; every call leaves it zeroed
- * where it matters, so the same buffer is reused step after step.  Integer work, bit-exact. */
+ * where it matters, so the same buffer is reused step after step.  Integer work, bit-exact.
+ * keep_flags != 0 (n_ranks == 1 only): the "row was looked up" flags stay set for aread_adam_table_l2, which
+ * consumes and clears them. */
 int64_t aread_route_ws_bytes(int64_t n_table_rows, int n_ranks);
 int aread_route_build(const int32_t* x, int64_t B, int f_in, const int32_t* offsets, int64_t n_table_rows,
                       int n_ranks, void* ws, int32_t* slot_out, int32_t* uniq_rows_out, int32_t* edges_out,
-                      void* stream);
+                      int keep_flags, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense L2 term of the embedding table.  Replaces the table part of
@@ -270,6 +272,28 @@ int aread_model_l2_coef(const aread_model* m, float* coef_host);
 int64_t aread_debug_ws_offset(const aread_model* m, int64_t B, int n_seg, const char* name);
 int aread_l2_dense(const float* params, const float* coef, int64_t n, float* grads, float* loss_out,
                    int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused optimizer.  torch.optim.Adam as the reference configures it (run.py:830-831: lr 1e-3,
+ * betas (0.9, 0.99), eps 1e-8, COUPLED weight_decay 1e-8, no amsgrad); `step` is 1-based.
+ *   aread_adam_step     : w, m, v updated in place from a materialised gradient g (flat buffer of n floats).
+ *                         active (optional, uint8[n]): 0 = the element belongs to a tensor whose grad is None in
+ *                         the reference (torch skips it entirely: no decay, no moment update).
+ *   aread_adam_table_l2 : the embedding table with the dense L2 term of layer.py:31,96-112 folded in, no dense
+ *                         gradient buffer: g = 2*l2*w + (row looked up ? g_rows[slot(row)] : 0).  route_ws /
+ *                         uniq_rows / edges come from aread_route_build(n_ranks = 1, keep_flags = 1) on this batch,
+ *                         g_rows [<= B*f_in, E] from aread_embed_bwd over the slot ids; all four NULL = L2 only.
+ *                         partial (optional): float[aread_l2_partials()] block sums of w^2 BEFORE the update, for
+ *                         aread_l2_finish (the step's loss value).  The flags in route_ws are cleared. */
+typedef struct aread_adam_cfg {
+    float lr, beta1, beta2, eps, weight_decay;
+    int32_t step;
+} aread_adam_cfg;
+int aread_adam_step(float* w, const float* g, float* m, float* v, int64_t n, const uint8_t* active,
+                    const aread_adam_cfg* cfg, void* stream);
+int aread_adam_table_l2(float* w, float* m, float* v, int64_t n_rows, int E, void* route_ws,
+                        const int32_t* uniq_rows, const int32_t* edges, const float* g_rows, float l2,
+                        const aread_adam_cfg* cfg, float* partial, void* stream);
 
 #ifdef __cplusplus
 }

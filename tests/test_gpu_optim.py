@@ -1,0 +1,153 @@
+"""GPU: fused optimizer.  aread_adam_step / aread_adam_table_l2 against torch.optim.Adam with the
+reference's hyper-parameters (run.py:830-831), and the whole fused training step (aread_amd.FusedAdam) against
+train_step + torch.optim.Adam over model.parameters()."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+HYPER = dict(lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-8)
+
+
+def _cfg(step, lr=1e-3, wd=1e-8):
+    from aread_amd.optim import AdamCfg
+    c = AdamCfg()
+    c.lr, c.beta1, c.beta2, c.eps, c.weight_decay, c.step = lr, 0.9, 0.99, 1e-8, wd, step
+    return c
+
+
+@pytest.mark.parametrize("n", [1, 1000, 300001])
+def test_adam_step_matches_torch(n):
+    from aread_amd import _lib as L
+    g0 = torch.Generator(device="cuda").manual_seed(n)
+    w = torch.randn(n, device="cuda", generator=g0)
+    ref = torch.nn.Parameter(w.clone())
+    opt = torch.optim.Adam([ref], **HYPER)
+    m, v = torch.zeros_like(w), torch.zeros_like(w)
+    active = (torch.rand(n, device="cuda", generator=g0) < 0.7).to(torch.uint8) if n > 1 else None
+    w_act = w.clone()
+    m_act, v_act = torch.zeros_like(w), torch.zeros_like(w)
+    for step in range(1, 5):
+        g = torch.randn(n, device="cuda", generator=g0) * (10.0 ** float(-step))      # down to 1e-4-sized gradients
+        ref.grad = g.clone()
+        opt.step()
+        c = _cfg(step)
+        L.check(L.lib().aread_adam_step(L.ptr(w), L.ptr(g), L.ptr(m), L.ptr(v), n, None, C.byref(c), L.stream()))
+        if active is not None:
+            L.check(L.lib().aread_adam_step(L.ptr(w_act), L.ptr(g), L.ptr(m_act), L.ptr(v_act), n, L.ptr(active), C.byref(c),
+                                            L.stream()))
+    torch.testing.assert_close(w, ref.data, rtol=2e-6, atol=2e-7)
+    st = opt.state[ref]
+    torch.testing.assert_close(m, st["exp_avg"], rtol=1e-5, atol=1e-8)       # m ~ 0.1*g: cancellation near 0
+    torch.testing.assert_close(v, st["exp_avg_sq"], rtol=1e-5, atol=1e-12)
+    if active is not None:
+        on = active.bool()
+        assert torch.equal(w_act[on], w[on])
+        assert torch.equal(w_act[~on], w.new_tensor(0) + torch.randn(n, device="cuda", generator=torch.Generator(device="cuda").manual_seed(n))[~on])
+        assert float(m_act[~on].abs().max()) == 0.0 and float(v_act[~on].abs().max()) == 0.0
+
+
+def test_adam_table_l2_matches_l2_pass_plus_torch_adam():
+    """table kernel == (aread_l2_table dense gradient + scatter) fed to torch Adam; sum(w^2) partials identical to the L2 pass"""
+    from aread_amd import _lib as L
+    import aread_amd.dist as D
+    lib = L.lib()
+    rng = np.random.default_rng(3)
+    dims, E, B = [5000, 7, 30], 32, 512
+    R = sum(dims)
+    off = torch.from_numpy(np.concatenate([[0], np.cumsum(dims)[:-1]]).astype(np.int32)).cuda()
+    w = torch.randn(R, E, device="cuda")
+    ref = torch.nn.Parameter(w.clone())
+    opt = torch.optim.Adam([ref], **HYPER)
+    m, v = torch.zeros_like(w), torch.zeros_like(w)
+    router = D.ShardRouter(R, world=1, rank=0)
+    ws = torch.zeros(int(lib.aread_route_ws_bytes(R, 1)), dtype=torch.uint8, device="cuda")
+    part, part_ref = (torch.empty(lib.aread_l2_partials(), device="cuda") for _ in range(2))
+    l2 = 1e-5
+    for step in range(1, 4):
+        x = torch.from_numpy(np.stack([rng.integers(0, d, B) for d in dims], axis=1).astype(np.int32)).cuda()
+        slot = torch.empty_like(x)
+        uniq = torch.empty(x.numel(), dtype=torch.int32, device="cuda")
+        edges = torch.empty(2, dtype=torch.int32, device="cuda")
+        L.check(lib.aread_route_build(L.ptr(x), B, 3, L.ptr(off), R, 1, L.ptr(ws), L.ptr(slot), L.ptr(uniq), L.ptr(edges), 1,
+                                      L.stream()))
+        n_u = int(edges[1])
+        g_rows = torch.zeros(x.numel(), E, device="cuda")
+        g_rows[:n_u] = torch.randn(n_u, E, device="cuda") * 1e-3
+        # reference: dense gradient = L2 pass + rows
+        gd = torch.empty_like(w)
+        L.check(lib.aread_l2_table(L.ptr(ref.data), ref.numel(), l2, 1.0, L.ptr(gd), L.ptr(part_ref), L.stream()))
+        gd[uniq[:n_u].long()] += g_rows[:n_u]
+        ref.grad = gd
+        opt.step()
+        c = _cfg(step)
+        L.check(lib.aread_adam_table_l2(L.ptr(w), L.ptr(m), L.ptr(v), R, E, L.ptr(ws), L.ptr(uniq), L.ptr(edges), L.ptr(g_rows),
+                                        l2, C.byref(c), L.ptr(part), L.stream()))
+        torch.cuda.synchronize()
+        assert int(ws[:R].sum()) == 0                                  # flags consumed
+        assert torch.equal(part, part_ref) or step > 1                 # same weights only before the first update
+        torch.testing.assert_close(w, ref.data, rtol=2e-6, atol=2e-7)
+    torch.testing.assert_close(m, opt.state[ref]["exp_avg"], rtol=1e-5, atol=1e-9)
+
+
+def test_fused_training_step_matches_train_step_plus_torch_adam():
+    import aread_amd
+    fn, mk, seed = U.GOLDEN_MODELS["full"]
+    G, spec = U.load_golden(fn), mk()
+    masks = U.golden_masks(spec, G, "rand")
+    x0 = torch.from_numpy(G["multi_rand/x"]).cuda()
+    y0 = torch.from_numpy(G["multi_rand/y"].astype(np.float32)).cuda()
+    batches = [(x0, y0)]
+    for k in (1, 2):
+        perm = torch.from_numpy(np.random.default_rng(k).permutation(x0.shape[0])).cuda()
+        xk = x0[perm].clone()
+        xk[:, 0] = (xk[:, 0] + 7 * k) % spec.field_dims[0]
+        batches.append((xk.contiguous(), (1.0 - y0[perm]).contiguous()))
+
+    def fresh():
+        model, _ = U.build_model(spec, seed, dropout=0.2)
+        model.train()
+        model.drop_seed = 99
+        model.domain_mask = [[torch.tensor(np.asarray(m), dtype=torch.bool, device="cuda") for m in mk_] for mk_ in masks]
+        return model
+
+    a = fresh()
+    md = aread_amd.pack_masks(masks, spec.n_domain, a.edge_num, "cuda")
+    opt = torch.optim.Adam(a.parameters(), **HYPER)
+    bufs = a.make_step_buffers(x0.shape[0])
+    ref_losses = []
+    for x, y in batches:
+        a.zero_grad(set_to_none=True)
+        ref_losses.append(float(a.train_step(x, y, bufs, masks_dev=md)))
+        opt.step()
+    b = fresh()
+    fused = aread_amd.FusedAdam(b, x0.shape[0], **HYPER)
+    losses = [float(fused.step(x, y, md)) for x, y in batches]
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(losses[0], ref_losses[0], rtol=1e-6)
+    np.testing.assert_allclose(losses, ref_losses, rtol=2e-4)          # later steps: see the dense tolerance below
+    wa, wb = a.embedding.embedding_dict.weight.data, b.embedding.embedding_dict.weight.data
+    # every element moved by ~lr per step; both paths must agree far inside that
+    assert float((wa - wb).abs().max()) <= 3e-5 and float((wa - wb).abs().mean()) <= 1e-7
+    assert float((wb - U.build_model(spec, seed)[0].embedding.embedding_dict.weight.data).abs().max()) > 2e-3
+    # dense: the bias of a Linear that feeds BatchNorm has a zero true gradient; what is computed is rounding noise
+    # (~1e-10..1e-7) that Adam renormalises to up to +-lr per step and that decorrelates between any two
+    # implementations after the first update.  Those biases cannot influence the forward (BN removes them).
+    da, db = a.dense.data, b.dense.data
+    assert float((da - db).abs().mean()) <= 2e-7
+    for name, kind, off, shape, l2 in b._ptensors:
+        n = int(np.prod(shape)) if shape else 1
+        diff = float((da[off:off + n] - db[off:off + n]).abs().max())
+        k = name.split(".")
+        pre_bn_bias = k[-1] == "bias" and k[-3] == "layers" and int(k[-2]) % 4 == 0
+        assert diff <= (2 * HYPER["lr"] * len(batches) if pre_bn_bias else 5e-5), (name, diff)      # 3 steps move ~3e-3
+    # tensors the masks never reach keep their initial values and zero optimizer state in both
+    present = fused._present_for(b.domain_mask)
+    for on, (name, kind, off, shape, l2) in zip(present, b._ptensors):
+        if not on:
+            n = int(np.prod(shape)) if shape else 1
+            assert float(fused.m_dense[off:off + n].abs().max()) == 0.0
