@@ -36,7 +36,9 @@ _SIGS = {
     "aread_route_ws_bytes": (C.c_int64, [C.c_int64, C.c_int]),
     "aread_route_build": (C.c_int, [i32p, C.c_int64, C.c_int, i32p, C.c_int64, C.c_int, vp, i32p, i32p, i32p, C.c_int, vp]),
     "aread_adam_step": (C.c_int, [f32p, f32p, f32p, f32p, C.c_int64, vp, vp, vp]),
-    "aread_adam_table_l2": (C.c_int, [f32p, f32p, f32p, C.c_int64, C.c_int, vp, i32p, i32p, f32p, C.c_float, vp, f32p, vp]),
+    "aread_adam_table_l2": (C.c_int, [f32p, f32p, f32p, C.c_int64, C.c_int, vp, i32p, i32p, f32p, C.c_float, vp, C.c_int, f32p,
+                                      vp]),
+    "aread_adam_row_partials": (C.c_int, []),
     "aread_l2_partials": (C.c_int, []),
     "aread_l2_table": (C.c_int, [f32p, C.c_int64, C.c_float, C.c_float, f32p, f32p, vp]),
     "aread_l2_finish": (C.c_int, [f32p, C.c_int, C.c_float, f32p, C.c_int, vp]),

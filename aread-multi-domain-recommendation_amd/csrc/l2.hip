@@ -7,6 +7,8 @@
 #define L2_THREADS 256
 #define L2_BLOCKS 2048
 
+typedef float l2_f4 __attribute__((ext_vector_type(4)));
+
 __global__ __launch_bounds__(L2_THREADS) void k_l2_table(const float* __restrict__ w, int64_t n, float gscale,
                                                          float* __restrict__ grad, float* __restrict__ partial) {
     const int64_t n4 = n >> 2;
@@ -15,9 +17,12 @@ __global__ __launch_bounds__(L2_THREADS) void k_l2_table(const float* __restrict
     float acc = 0.f;
     const int64_t stride = (int64_t)gridDim.x * L2_THREADS;
     for (int64_t i = (int64_t)blockIdx.x * L2_THREADS + threadIdx.x; i < n4; i += stride) {
-        const float4 v = w4[i];
+        const l2_f4 v = __builtin_nontemporal_load((const l2_f4*)(w4 + i));       // streamed once: bypass L2/MALL retention
         acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-        if (grad) g4[i] = make_float4(gscale * v.x, gscale * v.y, gscale * v.z, gscale * v.w);
+        if (grad) {
+            const l2_f4 g = {gscale * v.x, gscale * v.y, gscale * v.z, gscale * v.w};
+            __builtin_nontemporal_store(g, (l2_f4*)(g4 + i));
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {             // scalar tail
         const int64_t i = (n4 << 2) + threadIdx.x;

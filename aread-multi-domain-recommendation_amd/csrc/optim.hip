@@ -10,8 +10,22 @@
 #include "common.h"
 #include "route.h"
 
+// no implicit fma contraction in this file: phase 0 and phases 1 + 2 of the table update are different kernels and
+// must round identically (explicit __fmaf_rn where a fused op is meant)
+#pragma clang fp contract(off)
+
 #define AD_THREADS 256
 #define AD_BLOCKS 2048          // == aread_l2_partials(): the sum(w^2) partials reduce exactly like k_l2_table's
+
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load(const float4* p) {
+    const nt_f4 v = __builtin_nontemporal_load((const nt_f4*)p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void nt_store(float4* p, const float4 v) {
+    nt_f4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, (nt_f4*)p);
+}
 
 struct AdamK {
     float b1w, b2, b2w, eps, wd, step_size, sqrt_bc2;
@@ -51,6 +65,9 @@ __global__ __launch_bounds__(AD_THREADS) void k_adam(float* __restrict__ w, cons
     }
 }
 
+// PHASE 0: every row (looked-up rows add their gradient row).  PHASE 1: only rows NOT looked up by the batch -- runs
+// concurrently with the forward/backward, which read exactly the other rows.
+template <int PHASE>
 __global__ __launch_bounds__(AD_THREADS) void k_adam_table(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
                                                            int64_t n4, int e4, uint8_t* __restrict__ flags,
                                                            const int32_t* __restrict__ slotmap, const float4* __restrict__ g_rows,
@@ -61,20 +78,22 @@ __global__ __launch_bounds__(AD_THREADS) void k_adam_table(float* __restrict__ w
     float acc = 0.f;
     const int64_t stride = (int64_t)gridDim.x * AD_THREADS;
     for (int64_t i = (int64_t)blockIdx.x * AD_THREADS + threadIdx.x; i < n4; i += stride) {
-        float4 wi = w4[i], mi = m4[i], vi = v4[i];
-        acc += wi.x * wi.x + wi.y * wi.y + wi.z * wi.z + wi.w * wi.w;
         const int64_t row = i / e4;
         const int c = (int)(i - row * e4);
+        if (PHASE == 1 && flags[row]) continue;
+        float4 wi = nt_load(w4 + i), mi = nt_load(m4 + i), vi = nt_load(v4 + i);   // 1 GB stream: keep it out of L2/MALL
+        acc += wi.x * wi.x + wi.y * wi.y + wi.z * wi.z + wi.w * wi.w;
         float4 g = make_float4(l2x2 * wi.x, l2x2 * wi.y, l2x2 * wi.z, l2x2 * wi.w);
-        if (flags && flags[row]) {
+        if (PHASE == 0 && flags && flags[row]) {
             const float4 s = g_rows[(int64_t)slotmap[row] * e4 + c];
-            g.x += s.x; g.y += s.y; g.z += s.z; g.w += s.w;
+            g = make_float4(__fmaf_rn(l2x2, wi.x, s.x), __fmaf_rn(l2x2, wi.y, s.y), __fmaf_rn(l2x2, wi.z, s.z),
+                            __fmaf_rn(l2x2, wi.w, s.w));
         }
         adam1(wi.x, mi.x, vi.x, g.x, k);
         adam1(wi.y, mi.y, vi.y, g.y, k);
         adam1(wi.z, mi.z, vi.z, g.z, k);
         adam1(wi.w, mi.w, vi.w, g.w, k);
-        w4[i] = wi; m4[i] = mi; v4[i] = vi;
+        nt_store(w4 + i, wi); nt_store(m4 + i, mi); nt_store(v4 + i, vi);
     }
     if (!partial) return;
 #pragma unroll
@@ -85,6 +104,48 @@ __global__ __launch_bounds__(AD_THREADS) void k_adam_table(float* __restrict__ w
     if (threadIdx.x == 0) {
         float t = 0.f;
         for (int i = 0; i < AD_THREADS / WAVE; ++i) t += s[i];
+        partial[blockIdx.x] = t;
+    }
+}
+
+// PHASE 2: the looked-up rows only (after the backward): row uniq_rows[s] takes gradient row s; clears the flags.
+#define AD_ROW_BLOCKS 512
+__global__ __launch_bounds__(AD_THREADS) void k_adam_rows(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
+                                                          int e4, const int32_t* __restrict__ uniq_rows,
+                                                          const int32_t* __restrict__ edges, const float4* __restrict__ g_rows,
+                                                          uint8_t* __restrict__ flags, float l2x2, AdamK k,
+                                                          float* __restrict__ partial) {
+    float4* w4 = (float4*)w;
+    float4* m4 = (float4*)m;
+    float4* v4 = (float4*)v;
+    const int64_t n = (int64_t)edges[1] * e4;
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * AD_THREADS + threadIdx.x; i < n; i += (int64_t)AD_ROW_BLOCKS * AD_THREADS) {
+        const int64_t s = i / e4;
+        const int c = (int)(i - s * e4);
+        const int64_t row = uniq_rows[s];
+        const int64_t j = row * e4 + c;
+        float4 wi = w4[j], mi = m4[j], vi = v4[j];
+        acc += wi.x * wi.x + wi.y * wi.y + wi.z * wi.z + wi.w * wi.w;
+        const float4 gs = g_rows[i];
+        float4 g = make_float4(__fmaf_rn(l2x2, wi.x, gs.x), __fmaf_rn(l2x2, wi.y, gs.y), __fmaf_rn(l2x2, wi.z, gs.z),
+                               __fmaf_rn(l2x2, wi.w, gs.w));
+        adam1(wi.x, mi.x, vi.x, g.x, k);
+        adam1(wi.y, mi.y, vi.y, g.y, k);
+        adam1(wi.z, mi.z, vi.z, g.z, k);
+        adam1(wi.w, mi.w, vi.w, g.w, k);
+        w4[j] = wi; m4[j] = mi; v4[j] = vi;
+        if (c == 0) flags[row] = 0;
+    }
+    if (!partial) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    __shared__ float sm[AD_THREADS / WAVE];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < AD_THREADS / WAVE; ++i) t += sm[i];
         partial[blockIdx.x] = t;
     }
 }
@@ -111,11 +172,17 @@ extern "C" int aread_adam_step(float* w, const float* g, float* m, float* v, int
 
 extern "C" int aread_adam_table_l2(float* w, float* m, float* v, int64_t n_rows, int E, void* route_ws,
                                    const int32_t* uniq_rows, const int32_t* edges, const float* g_rows, float l2,
-                                   const aread_adam_cfg* cfg, float* partial, void* stream) {
+                                   const aread_adam_cfg* cfg, int phase, float* partial, void* stream) {
     AR_CHECK_ARG(w && m && v && n_rows > 0 && E > 0 && E % 4 == 0, "aread_adam_table_l2: bad arguments");
     AR_CHECK_ARG((((uintptr_t)w | (uintptr_t)m | (uintptr_t)v | (uintptr_t)g_rows) & 15) == 0, "aread_adam_table_l2: alignment");
-    AR_CHECK_ARG((route_ws == nullptr) == (g_rows == nullptr) && (route_ws == nullptr) == (uniq_rows == nullptr) &&
-                 (route_ws == nullptr) == (edges == nullptr), "aread_adam_table_l2: route_ws, uniq_rows, edges and g_rows go together");
+    AR_CHECK_ARG(phase >= 0 && phase <= 2, "aread_adam_table_l2: phase=%d", phase);
+    if (phase == 0)
+        AR_CHECK_ARG((route_ws == nullptr) == (g_rows == nullptr) && (route_ws == nullptr) == (uniq_rows == nullptr) &&
+                     (route_ws == nullptr) == (edges == nullptr),
+                     "aread_adam_table_l2: route_ws, uniq_rows, edges and g_rows go together");
+    else
+        AR_CHECK_ARG(route_ws && (phase == 1 || (uniq_rows && edges && g_rows)), "aread_adam_table_l2: phase %d needs the routing "
+                     "workspace%s", phase, phase == 2 ? ", uniq_rows, edges and g_rows" : "");
     AdamK k;
     AR_CHECK_ARG(adam_consts(cfg, &k) == 0, "aread_adam_table_l2: bad optimizer configuration");
     uint8_t* flags = nullptr;
@@ -128,12 +195,25 @@ extern "C" int aread_adam_table_l2(float* w, float* m, float* v, int64_t n_rows,
         slotmap = (const int32_t*)((char*)route_ws + L.off_slotmap);
     }
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_adam_table, dim3(AD_BLOCKS), dim3(AD_THREADS), 0, st, w, m, v, n_rows * (E / 4), E / 4, flags, slotmap,
-                       (const float4*)g_rows, 2.0f * l2, k, partial);
-    AR_LAUNCH_CHECK();
-    if (route_ws) {
-        hipLaunchKernelGGL(k_route_clear, dim3(128), dim3(256), 0, st, uniq_rows, edges, 1, flags);
+    const int e4 = E / 4;
+    if (phase == 0) {
+        hipLaunchKernelGGL(k_adam_table<0>, dim3(AD_BLOCKS), dim3(AD_THREADS), 0, st, w, m, v, n_rows * e4, e4, flags, slotmap,
+                           (const float4*)g_rows, 2.0f * l2, k, partial);
+        AR_LAUNCH_CHECK();
+        if (route_ws) {
+            hipLaunchKernelGGL(k_route_clear, dim3(128), dim3(256), 0, st, uniq_rows, edges, 1, flags);
+            AR_LAUNCH_CHECK();
+        }
+    } else if (phase == 1) {
+        hipLaunchKernelGGL(k_adam_table<1>, dim3(AD_BLOCKS), dim3(AD_THREADS), 0, st, w, m, v, n_rows * e4, e4, flags, slotmap,
+                           (const float4*)nullptr, 2.0f * l2, k, partial);
+        AR_LAUNCH_CHECK();
+    } else {
+        hipLaunchKernelGGL(k_adam_rows, dim3(AD_ROW_BLOCKS), dim3(AD_THREADS), 0, st, w, m, v, e4, uniq_rows, edges,
+                           (const float4*)g_rows, flags, 2.0f * l2, k, partial);
         AR_LAUNCH_CHECK();
     }
     return AREAD_OK;
 }
+
+extern "C" int aread_adam_row_partials(void) { return AD_ROW_BLOCKS; }

@@ -44,6 +44,7 @@ class FusedAdam:
         self.zero_off = torch.zeros(f_in, dtype=torch.int32, device=dev)
         self.sort_ws = torch.empty(int(lib.aread_embed_bwd_ws_bytes(B, f_in, table.shape[1])), dtype=torch.uint8, device=dev)
         self.part = torch.empty(lib.aread_l2_partials(), dtype=torch.float32, device=dev)
+        self.part_rows = torch.empty(lib.aread_adam_row_partials(), dtype=torch.float32, device=dev)
         self.total = torch.zeros(1, dtype=torch.float32, device=dev)
         self._side = torch.cuda.Stream(device=dev)
         self._masks_key, self._present = None, None
@@ -101,17 +102,24 @@ class FusedAdam:
                                              emb.one_hot_field_num, emb.multi_hot_field_num, emb.seq_maxlen, emb._pool,
                                              L.ptr(plan.sample_row), L.ptr(self.sort_ws), L.stream()))
             self.g_rows.zero_()
+            # rows the batch does not touch: L2-only Adam update now, concurrently with the forward/backward (the
+            # gather reads exactly the other rows)
+            self.t_table += 1
+            cfg = self._cfg(self.t_table)
+            L.check(lib.aread_adam_table_l2(L.ptr(table), L.ptr(self.m_table), L.ptr(self.v_table), table.shape[0], E,
+                                            L.ptr(self.route_ws), None, None, None, m.l2_reg_embedding, C.byref(cfg), 1,
+                                            L.ptr(self.part), L.stream()))
         m.step_local(x, y, b, masks_dev=masks_dev, with_dense_l2=False, presort=False, plan=plan, table_pass=False)
         main.wait_stream(side)
         seq = emb.seq_maxlen if emb._pool != 0 else 1
         L.check(lib.aread_embed_bwd_reduce(Bn, f_in, E, seq, L.ptr(b["de"]), L.ptr(self.g_rows), L.ptr(self.sort_ws),
                                            L.stream()))
-        self.t_table += 1
-        cfg = self._cfg(self.t_table)
         L.check(lib.aread_adam_table_l2(L.ptr(table), L.ptr(self.m_table), L.ptr(self.v_table), table.shape[0], E,
                                         L.ptr(self.route_ws), L.ptr(self.uniq), L.ptr(self.edges), L.ptr(self.g_rows),
-                                        m.l2_reg_embedding, C.byref(cfg), L.ptr(self.part), L.stream()))
+                                        m.l2_reg_embedding, C.byref(cfg), 2, L.ptr(self.part_rows), L.stream()))
         L.check(lib.aread_l2_finish(L.ptr(self.part), self.part.numel(), m.l2_reg_embedding, L.ptr(b["reg"]), 0, L.stream()))
+        L.check(lib.aread_l2_finish(L.ptr(self.part_rows), self.part_rows.numel(), m.l2_reg_embedding, L.ptr(b["reg"]), 1,
+                                    L.stream()))
         m.step_finish(b)                                    # dense gradients complete
         m.add_dense_l2(b)                                   # reg += dense terms, gdense += 2*coef*w
         torch.add(b["loss"][:1], b["reg"][:1], out=self.total)

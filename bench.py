@@ -353,7 +353,7 @@ def measure_fused_adam(model, batches, masks_dev, B, L, steps=30):
     cfg = opt._cfg(100)
     fn = lambda: L.check(L.lib().aread_adam_table_l2(L.ptr(table), L.ptr(opt.m_table), L.ptr(opt.v_table), table.shape[0],
                                                      table.shape[1], None, None, None, None, model.l2_reg_embedding,
-                                                     C.byref(cfg), L.ptr(opt.part), L.stream()))
+                                                     C.byref(cfg), 0, L.ptr(opt.part), L.stream()))
     t = _time_kernel(fn, iters=20)
     alg = 6.0 * table.numel() * 4
     return {"ms_per_step": round(dt * 1e3, 4), "samples_per_s": round(B / dt, 1), "optimizer": "Adam(lr 1e-3, betas (0.9,0.99), "

@@ -284,7 +284,13 @@ int aread_l2_dense(const float* params, const float* coef, int64_t n, float* gra
  *                         uniq_rows / edges come from aread_route_build(n_ranks = 1, keep_flags = 1) on this batch,
  *                         g_rows [<= B*f_in, E] from aread_embed_bwd over the slot ids; all four NULL = L2 only.
  *                         partial (optional): float[aread_l2_partials()] block sums of w^2 BEFORE the update, for
- *                         aread_l2_finish (the step's loss value).  The flags in route_ws are cleared. */
+ *                         aread_l2_finish (the step's loss value).  The flags in route_ws are cleared.
+ *                         phase 0 = the whole table in one pass (after the backward);
+ *                         phase 1 = only the rows the batch did NOT look up: needs nothing from the backward and
+ *                                   touches no row the gather reads, so it overlaps the forward/backward on another
+ *                                   stream (g_rows/uniq_rows/edges unused);
+ *                         phase 2 = the looked-up rows only (after the backward; clears the flags; partial holds
+ *                                   aread_adam_row_partials() entries).  Phases 1 + 2 == phase 0. */
 typedef struct aread_adam_cfg {
     float lr, beta1, beta2, eps, weight_decay;
     int32_t step;
@@ -293,7 +299,8 @@ int aread_adam_step(float* w, const float* g, float* m, float* v, int64_t n, con
                     const aread_adam_cfg* cfg, void* stream);
 int aread_adam_table_l2(float* w, float* m, float* v, int64_t n_rows, int E, void* route_ws,
                         const int32_t* uniq_rows, const int32_t* edges, const float* g_rows, float l2,
-                        const aread_adam_cfg* cfg, float* partial, void* stream);
+                        const aread_adam_cfg* cfg, int phase, float* partial, void* stream);
+int aread_adam_row_partials(void);
 
 #ifdef __cplusplus
 }

@@ -64,7 +64,9 @@ def test_adam_table_l2_matches_l2_pass_plus_torch_adam():
     ref = torch.nn.Parameter(w.clone())
     opt = torch.optim.Adam([ref], **HYPER)
     m, v = torch.zeros_like(w), torch.zeros_like(w)
-    router = D.ShardRouter(R, world=1, rank=0)
+    w2, m2, v2 = w.clone(), m.clone(), v.clone()                     # the same update in two phases
+    part1 = torch.empty(lib.aread_l2_partials(), device="cuda")
+    part2 = torch.empty(lib.aread_adam_row_partials(), device="cuda")
     ws = torch.zeros(int(lib.aread_route_ws_bytes(R, 1)), dtype=torch.uint8, device="cuda")
     part, part_ref = (torch.empty(lib.aread_l2_partials(), device="cuda") for _ in range(2))
     l2 = 1e-5
@@ -85,9 +87,20 @@ def test_adam_table_l2_matches_l2_pass_plus_torch_adam():
         ref.grad = gd
         opt.step()
         c = _cfg(step)
+        # phase 1 (rows not looked up) + phase 2 (looked-up rows) first: they need the flags that phase 0 clears
+        L.check(lib.aread_adam_table_l2(L.ptr(w2), L.ptr(m2), L.ptr(v2), R, E, L.ptr(ws), None, None, None, l2, C.byref(c), 1,
+                                        L.ptr(part1), L.stream()))
+        flags_between = int(ws[:R].sum())
+        L.check(lib.aread_adam_table_l2(L.ptr(w2), L.ptr(m2), L.ptr(v2), R, E, L.ptr(ws), L.ptr(uniq), L.ptr(edges),
+                                        L.ptr(g_rows), l2, C.byref(c), 2, L.ptr(part2), L.stream()))
+        assert flags_between == n_u and int(ws[:R].sum()) == 0
+        L.check(lib.aread_route_build(L.ptr(x), B, 3, L.ptr(off), R, 1, L.ptr(ws), L.ptr(slot), L.ptr(uniq), L.ptr(edges), 1,
+                                      L.stream()))
         L.check(lib.aread_adam_table_l2(L.ptr(w), L.ptr(m), L.ptr(v), R, E, L.ptr(ws), L.ptr(uniq), L.ptr(edges), L.ptr(g_rows),
-                                        l2, C.byref(c), L.ptr(part), L.stream()))
+                                        l2, C.byref(c), 0, L.ptr(part), L.stream()))
         torch.cuda.synchronize()
+        assert torch.equal(w, w2) and torch.equal(m, m2) and torch.equal(v, v2)
+        np.testing.assert_allclose(float(part1.double().sum() + part2.double().sum()), float(part.double().sum()), rtol=1e-6)
         assert int(ws[:R].sum()) == 0                                  # flags consumed
         assert torch.equal(part, part_ref) or step > 1                 # same weights only before the first update
         torch.testing.assert_close(w, ref.data, rtol=2e-6, atol=2e-7)
