@@ -335,7 +335,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm(const GemmP p) {
 // ================================================================================================
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-#define BF3_PITCH 40        // bf16 elements per LDS row
+// LDS image of a split-bf16 operand tile [ROWS][32 k]: four k-planes of [ROWS][8 bf16 = one 16-B slot]; plane f keeps
+// row r in slot r ^ (2*f).  With that XOR both the ds_read_b128 fragment reads (16-lane groups {0-3,12-15,20-27}, ...:
+// every group sees all 16 fragment rows once, on two neighbouring planes) and the ds_write_b64 staging stores
+// (16 contiguous lanes = 2 rows x 4 planes x 2 halves) touch every bank once: conflict-free, no padding.
+__device__ __forceinline__ int bf3_off(int rows, int row, int plane) { return (plane * rows + (row ^ (2 * plane))) * 8; }
 
 template <int ROWS>
 struct Bf3Loader {
@@ -381,8 +385,9 @@ struct Bf3Loader {
                     h[i] = (__bf16)x[i];
                     l[i] = (__bf16)(x[i] - (float)h[i]);
                 }
-                *(bf16x4*)(hi + row * BF3_PITCH + 4 * kq) = h;
-                *(bf16x4*)(lo + row * BF3_PITCH + 4 * kq) = l;
+                const int o = bf3_off(ROWS, row, kq >> 1) + 4 * (kq & 1);
+                *(bf16x4*)(hi + o) = h;
+                *(bf16x4*)(lo + o) = l;
             }
         }
     }
@@ -392,12 +397,12 @@ template <int NI>
 __global__ __launch_bounds__(GEMM_THREADS) void k_gemm_bf3(const GemmP p) {
     constexpr int TM = 64, TN = 16 * NI;
     constexpr int STAGE_B = 4 * 16 * (TN + 4) * 4;       // epilogue staging (bytes), overlays the operand tiles
-    constexpr int OPER_B = 2 * (TM + TN) * BF3_PITCH * 2;
+    constexpr int OPER_B = 2 * (TM + TN) * GEMM_BK * 2;
     __shared__ __attribute__((aligned(16))) char s_lds[OPER_B > STAGE_B ? OPER_B : STAGE_B];
     __bf16* Ah = (__bf16*)s_lds;
-    __bf16* Al = Ah + TM * BF3_PITCH;
-    __bf16* Bh = Al + TM * BF3_PITCH;
-    __bf16* Bl = Bh + TN * BF3_PITCH;
+    __bf16* Al = Ah + TM * GEMM_BK;
+    __bf16* Bh = Al + TM * GEMM_BK;
+    __bf16* Bl = Bh + TN * GEMM_BK;
     __shared__ float s_red[4][TN];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -440,8 +445,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm_bf3(const GemmP p) {
     };
     load_tiles(0);
     const int fr = lane & 15, fk = lane >> 4;              // fragment: row fr, k = 8*fk .. 8*fk+7
-    const int a_off = (wave * 16 + fr) * BF3_PITCH + 8 * fk;
-    const int b_off = fr * BF3_PITCH + 8 * fk;
+    const int a_off = bf3_off(TM, wave * 16 + fr, fk);
+    const int b_off = bf3_off(TN, fr, fk);                 // + i*16 rows: the XOR only touches the low 3 row bits
     for (int k0 = 0; k0 < k_end; k0 += GEMM_BK) {
         la.store(Ah, Al);
         lb.store(Bh, Bl);
@@ -450,8 +455,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm_bf3(const GemmP p) {
         const bf16x8 ah = *(const bf16x8*)(Ah + a_off), al = *(const bf16x8*)(Al + a_off);
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const bf16x8 bh = *(const bf16x8*)(Bh + b_off + i * 16 * BF3_PITCH);
-            const bf16x8 bl = *(const bf16x8*)(Bl + b_off + i * 16 * BF3_PITCH);
+            const bf16x8 bh = *(const bf16x8*)(Bh + b_off + i * 16 * 8);
+            const bf16x8 bl = *(const bf16x8*)(Bl + b_off + i * 16 * 8);
             acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[i], 0, 0, 0);
             acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[i], 0, 0, 0);
             acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[i], 0, 0, 0);

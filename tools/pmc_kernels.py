@@ -1,5 +1,6 @@
-"""Run the three roofline kernels a few times each (for rocprofv3 --pmc passes): expert-L1 forward GEMM at the
-bench shape, the table L2 pass and the embedding gather."""
+"""Run the roofline kernels a few times each (for rocprofv3 --pmc passes): expert-L1 forward GEMM at the bench shape
+(fp32 MFMA and split-bf16), the table L2 pass, the fused table optimizer pass and the embedding gather."""
+import ctypes as ct
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -20,7 +21,13 @@ x, _ = synth.amazon_batch(spec, rng, 8192)
 xs = torch.from_numpy(x).cuda()
 off = torch.from_numpy(spec.offsets().astype(np.int32)).cuda()
 out = torch.empty(8192 * 9 * 32, device="cuda")
+from aread_amd.optim import AdamCfg
+cfg = AdamCfg(); cfg.lr, cfg.beta1, cfg.beta2, cfg.eps, cfg.weight_decay, cfg.step = 1e-3, 0.9, 0.99, 1e-8, 1e-8, 10
+mom, var = torch.zeros_like(table), torch.zeros_like(table)
 for _ in range(5):
+    L.check(L.lib().aread_gemm_bf16x3(L.ptr(A), K, M * K, L.ptr(B), K, N * K, L.ptr(C), N, M * N, None, 0, M, N, K, 1, 0, L.stream()))
+    L.check(L.lib().aread_adam_table_l2(L.ptr(table), L.ptr(mom), L.ptr(var), R, 32, None, None, None, None, 1e-5, ct.byref(cfg), 0,
+                                        L.ptr(part), L.stream()))
     L.check(L.lib().aread_gemm(L.ptr(A), K, M * K, 1, L.ptr(B), K, N * K, 1, L.ptr(C), N, M * N, None, 0, M, N, K, 1, 0, L.stream()))
     L.check(L.lib().aread_l2_table(L.ptr(table), table.numel(), 1e-5, 1.0, L.ptr(grad), L.ptr(part), L.stream()))
     L.check(L.lib().aread_embed_fwd(L.ptr(xs), 8192, 17, L.ptr(off), L.ptr(table), R, 32, 7, 2, 5, 2, None, 8192, L.ptr(out), None,
