@@ -562,15 +562,38 @@ __global__ __launch_bounds__(256) void k_rowwise_bwd(const RowwiseBwdP p) {
                 }
             }
         }
+        // ds_i = dc_i . e with dc_i = dcn + sum_{j>i} w_j ds_j  =>  ds_i = (dcn . e) + sum_{j>i} ds_j (w_j . e): the row's
+        // dot products are independent of the recursion, so one interleaved wave reduction replaces NC chained ones
+        float dots[NCA];                       // [0] = dcn . e, [j] = w_j . e (j >= 1)
+#pragma unroll
+        for (int j = 0; j < NCA; ++j) dots[j] = 0.f;
+#pragma unroll
+        for (int v = 0; v < RW_MAXV; ++v) {
+            const int ch = lane + 64 * v;
+            dots[0] += dot4(dc[v], e[v]);
+#pragma unroll
+            for (int j = 1; j < NC; ++j)
+                if (ch < d4) dots[j] += dot4(((const float4*)(p.cn_w + (int64_t)j * p.D))[ch], e[v]);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+            for (int j = 0; j < NCA; ++j) dots[j] += __shfl_xor(dots[j], o);
+        }
+        float dsv[NCA];
+#pragma unroll
+        for (int i = NC - 1; i >= 0; --i) {
+            float t = dots[0];
+#pragma unroll
+            for (int j = NC - 1; j > i; --j) t += dsv[j] * dots[j];
+            dsv[i] = t;
+        }
 #pragma unroll
         for (int i = NC - 1; i >= 0; --i) {
             {
                 const float xw = p.xw[(int64_t)i * p.rows + row];
                 const float4* w4 = (const float4*)(p.cn_w + (int64_t)i * p.D);
-                float ds = 0.f;
-#pragma unroll
-                for (int v = 0; v < RW_MAXV; ++v) ds += dot4(dc[v], e[v]);
-                ds = wave_sum(ds);
+                const float ds = dsv[i];
 #pragma unroll
                 for (int v = 0; v < RW_MAXV; ++v) {
                     const int ch = lane + 64 * v;

@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--domain-dist", default="proportional", choices=["proportional", "uniform"])
     ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3"],
                     help="GEMM arithmetic of the expert/tower forward+dgrad: exact fp32 MFMA or split-bf16 (3 products)")
+    ap.add_argument("--step-only", action="store_true", help="profiling: run only the warm-up + timed steps (no roofline "
+                    "micro-loops, no forward-only / fused-optimizer extras, no CPU baseline), so rocprofv3 sees the pure step")
     ap.add_argument("--force-dp", action="store_true", help="use the multi-GPU code path even with one rank (testing)")
     ap.add_argument("--table", default="auto", choices=["auto", "replicated", "sharded"],
                     help="multi-GPU embedding table: replicated (all_gather of ids/dE) or row-sharded (all_to_all lookup, "
@@ -221,14 +223,23 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = world * B * args.steps / dt
 
+    if args.step_only:
+        if rank == 0:
+            os.write(json_fd, (json.dumps({"metric": "CTR samples/s fwd+bwd, AREAD 25-domain batch=8192", "value": round(value, 1),
+                                           "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                                           "ms_per_step": round(ms_per_step, 4), "note": "--step-only profiling run"}) + "\n").encode())
+        if use_dp:
+            dist.destroy_process_group()
+        return
     # ---- roofline of the dominant kernel: the dense-L2 table sweep (read table, write dense gradient) ----
     gemm = measure_gemm_kernel(model, bufs, L, B, args.precision)
+    wgrad = measure_wgrad_kernel(model, bufs, L, B)
     l2pass = measure_l2_kernel(model, bufs, L)
     gather = measure_gather_kernel(model, xs, bufs, L)
     big_x = torch.cat([bt[0] for bt in batches] * 2, dim=0)                  # 65 536 samples: latency amortised
     gather_big = measure_gather_kernel(model, big_x, bufs, L)
     # `roofline` = the single most expensive kernel launch of the step (longest average duration, cf. profiles/)
-    roofline = max((gemm, l2pass), key=lambda r: r["avg_launch_us"])
+    roofline = max((gemm, wgrad, l2pass), key=lambda r: r["avg_launch_us"])
 
     out = {
         "metric": "CTR samples/s fwd+bwd, AREAD 25-domain batch=8192", "value": round(value, 1), "unit": "samples/s",
@@ -247,11 +258,12 @@ def main():
                                                    ": row-sharded table (r % P), all_to_all(ids,rows,row grads)+"
                                                    "reduce_scatter(dense grads) over RCCL, 2 host reads/step"),
                    **({"table_variants_ms": dp_state["times_ms"]} if "times_ms" in dp_state else {})},
-        "roofline": roofline, "gemm_roofline": gemm, "l2_table_roofline": l2pass, "gather_roofline": gather,
+        "roofline": roofline, "gemm_roofline": gemm, "wgrad_roofline": wgrad, "l2_table_roofline": l2pass, "gather_roofline": gather,
         "gather_roofline_b65536": gather_big,
         "loss": round(loss, 6),
     }
     if world == 1 and not use_dp:
+        out["forward_only"] = measure_forward_only(model, batches, bufs, masks_dev, B)      # BASELINE configs[1]
         # beyond the metric: the same step WITH the optimizer, fused (modifies the parameters: runs last)
         out["train_step_with_fused_adam"] = measure_fused_adam(model, batches, masks_dev, B, L)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -321,6 +333,28 @@ def measure_gemm_kernel(model, bufs, L, B, precision):
             "mfma": "v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate)"}
 
 
+def measure_wgrad_kernel(model, bufs, L, B):
+    """Expert layer 1 weight gradient dW1[1024,288] = dZ[rows,1024]^T . E[rows,288] (k_gemm<6,false,false>: fp32 MFMA, both
+    operands row-contiguous, K = the batch rows cut into 16 split-K slices exactly as the model's backward launches it --
+    expressed here through the public grouped entry point: one group per slice).  The longest single launch of the step."""
+    rows, D = bufs["e"].shape
+    h1 = model.expert_dims[0] * int(model._cfg.n_expert)
+    k_split = 16
+    k_chunk = rows // k_split
+    dz = torch.randn((rows, h1), device=bufs["e"].device)
+    slab = torch.empty((k_split, h1, D), device=dz.device)
+    fn = lambda: L.check(L.lib().aread_gemm(L.ptr(dz), h1, k_chunk * h1, 0, L.ptr(bufs["e"]), D, k_chunk * D, 0, L.ptr(slab), D,
+                                            h1 * D, None, 0, h1, D, k_chunk, k_split, 0, L.stream()))
+    t = _time_kernel(fn)
+    alg = 2.0 * D * h1 * B
+    ach = alg / t / 1e12
+    return {"kernel": "k_gemm<6,false,false> (expert layer 1 weight gradient, split-K 16)", "bound": "mfma",
+            "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4),
+            "traffic": _pmc_traffic("k_gemm<6,false,false>"), "algorithmic_flops_per_launch": alg,
+            "executed_flops_per_launch": 2.0 * D * h1 * k_chunk * k_split, "avg_launch_us": round(t * 1e6, 2),
+            "mfma": "v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate)"}
+
+
 def measure_l2_kernel(model, bufs, L):
     table = model.embedding.embedding_dict.weight
     n = table.numel()
@@ -333,6 +367,24 @@ def measure_l2_kernel(model, bufs, L):
     return {"kernel": "k_l2_table", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic("k_l2_table"), "algorithmic_bytes_per_launch": alg,
             "avg_launch_us": round(t * 1e6, 2)}
+
+
+def measure_forward_only(model, batches, bufs, masks_dev, B, steps=50):
+    """BASELINE configs[1]: row plan + embedding gather + MMoE/HEI forward + bagging BCE of the 25-domain batch
+    (train mode: per-domain batch statistics, dropout, running-stat update), no backward."""
+    def fwd(i):
+        x, y = batches[i % len(batches)][:2]
+        model._run(x, 0, bufs["n_seg"], None, masks_dev, False, y=y, loss_out=bufs["loss"], ws=bufs["ws"], probs=bufs["probs"],
+                   e=bufs["e"])
+    for i in range(5):
+        fwd(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        fwd(i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"ms_per_step": round(dt * 1e3, 4), "samples_per_s": round(B / dt, 1), "mode": "train-mode forward + loss, eager"}
 
 
 def measure_fused_adam(model, batches, masks_dev, B, L, steps=30):
