@@ -110,7 +110,7 @@ class Trainer:
                 model.zero_grad()
                 loss.backward()
                 optimizer.step()
-                self.trace.append(("warmup_loss", float(loss)))
+                self.trace.append(("warmup_loss", float(loss.detach())))
         for i, d in enumerate(self.train_s.batch_seq):
             X, y = self.train_s.next(d)
             if (epoch_i == 0 and i == 0) or ((i + 1) % regroup == 0):
@@ -123,7 +123,7 @@ class Trainer:
             model.zero_grad()
             loss.backward()
             optimizer.step()
-            self.trace.append(("train_loss", float(loss)))
+            self.trace.append(("train_loss", float(loss.detach())))
 
     def _regroup(self, criterion):
         """run.py:612-661"""
@@ -155,7 +155,7 @@ class Trainer:
                         pred = model(X, mode="domain_with_mask", current_mask=mask, domain_i=d)
                         loss = criterion(pred.squeeze(), y.squeeze().float()) + model.get_regularization_loss(device=self.device)
                         model.add_eval_loss(loss.mean().item(), d=d, mask_z=z)
-                        self.trace.append(("eval_loss", float(loss)))
+                        self.trace.append(("eval_loss", float(loss.detach())))
         model.update_all_mask(regroup_times=self.regroup_times)
         model.reset_for_mask_update()
         model.load_model_state()

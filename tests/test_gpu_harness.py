@@ -83,3 +83,51 @@ def test_metrics_match_sklearn():
     p = np.round(rng.random(500), 2).astype(np.float32)     # ties on purpose
     assert abs(_auc(t, p) - roc_auc_score(t, p)) < 1e-12
     assert abs(_logloss(t, p) - log_loss(t, p)) < 1e-9
+
+
+def test_csv_to_trained_model_end_to_end(tmp_path):
+    """prepared CSV -> data.read_split_data -> AREAD (HIP) -> Trainer.main: the flow of the reference's main.py/run.py
+    (get_data, get_model, main) on a small synthetic Amazon-layout CSV with a learnable label."""
+    import contextlib, io, types
+    import pandas as pd
+    import aread_amd
+    from aread_amd import data as D
+    from aread_amd.harness import Trainer
+    rng = np.random.default_rng(4)
+    n, n_item, n_dom = 3000, 60, 4
+    item = rng.integers(0, n_item, n)
+    dom = rng.integers(0, n_dom, n)
+    w_item, w_dom = rng.standard_normal(n_item), rng.standard_normal(n_dom)
+    p = 1.0 / (1.0 + np.exp(-(1.5 * w_item[item] + w_dom[dom])))
+    frame = pd.DataFrame(dict(
+        userid=np.arange(n), itemid=item, weekday=rng.integers(0, 7, n), domain=dom, sales_chart=rng.integers(0, 5, n),
+        sales_rank=rng.integers(0, 3, n), brand=rng.integers(0, 9, n), price=rng.integers(0, 6, n),
+        user_pos_6month_seq=[str(rng.integers(0, n_item, rng.integers(0, 7)).tolist()) for _ in range(n)],
+        user_neg_6month_seq=[str(rng.integers(0, n_item, rng.integers(0, 3)).tolist()) for _ in range(n)],
+        label=(rng.random(n) < p).astype(int), timestamp=np.arange(n)))
+    path = tmp_path / "amazon_like.csv"
+    frame.to_csv(path, index=False)
+    t = D.read_split_data(str(path), "amazon", seq_maxlen=5, itemid_all=n_item)
+    cfg = types.SimpleNamespace(bs=128, lr=5e-3, wd=1e-8, update_lr=1e-2, warm_up_interval=0.5, regroup_interval=2.0,
+                                regroup_update_step=2, regroup_eval_step=2, candidate_mask_num=2.0, random_modify_sigma=0.2,
+                                init_active_percent=0.7, early_stop=2, dataset_name="amazon", embed_dim=16,
+                                aread_precision="bf16x3",
+                                # the reference's config.py attributes the model reads (config.py:22-57)
+                                domain_size={"amazon": [int(c) for c in np.bincount(dom, minlength=n_dom)]}, use_dcn=True,
+                                use_atten=True, n_cross_layers=3, mmoe_n_expert=4, atten_embed_dim=64, att_layer_num=3,
+                                att_head_num=2, att_res=True)
+    np.random.seed(0); torch.manual_seed(0)
+    model = aread_amd.AREAD(t.one_hot_feature_dims, 16, t.multi_hot_dict, (3, 6, 12), t.n_domain, "mmoe", (64, 32, 16),
+                            ((16, 8), (8, 8), (8, 4)), t.domain_idx, device="cuda", config=cfg).to("cuda")
+    model.reset_for_mask_update()
+    s = D.domain_streams(t, cfg.bs, "cuda")
+    tr = Trainer(model, cfg, s["train"], s["valid"], test=s["test"], device="cuda", log=lambda *a: None)
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = tr.main(epochs=3, save_path=str(tmp_path / "ckpt.pth"))
+    assert all(np.isfinite(r["total_loss"]) for r in res)
+    assert max(r["total_auc"] for r in res) > 0.6, [r["total_auc"] for r in res]        # it learns the item/domain effect
+    test = tr.test("test")
+    assert 0.0 < test["total_loss"] < 1.0 and np.isfinite(test["mean_auc"])
+    ck = torch.load(str(tmp_path / "ckpt.pth"), weights_only=False)                      # a file this test wrote itself
+    assert set(ck) >= {"epoch", "state_dict", "best_auc", "optimizer", "domain_mask"}
+    assert "embedding.embedding_dict.weight" in ck["state_dict"]
