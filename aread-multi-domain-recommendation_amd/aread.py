@@ -405,7 +405,7 @@ class AREAD(HempMixin, nn.Module):
         return pack_masks(masks, self.n_domain, self._edge_count, device)
 
     def _run(self, x, mode_id, n_seg, domain, masks_dev, want_gates, y=None, seg_weight=None, loss_out=None,
-             ws=None, plan=None, probs=None, e=None, e_ready=False):
+             ws=None, plan=None, probs=None, e=None, e_ready=False, async_fwd=False):
         """plan + embedding + dense forward.  Returns a _CallState (buffers owned by it).
         e_ready: `e` already holds the pooled embedding in plan order (row-sharded table, dist.ShardedTableStep)."""
         L.require_device(x, self.dense, self.embedding.embedding_dict.weight)
@@ -442,6 +442,7 @@ class AREAD(HempMixin, nn.Module):
         call.params, call.stats, call.nbt = L.ptr(self.dense), L.ptr(self.bn_stats), L.ptr(self.bn_nbt)
         call.ws, call.probs, call.gate_stats = L.ptr(ws), L.ptr(st.probs), L.ptr(gate)
         call.y, call.seg_weight, call.loss_out = L.ptr(y), L.ptr(seg_weight), L.ptr(loss_out)
+        call.async_tail = 2 if async_fwd else 0          # fused step: loss / running stats finish on the library's side stream
         st.call = call
         st.keep = (masks_dev, gate, y, seg_weight, loss_out)
         L.check(lib.aread_forward(self._handle, C.byref(call), L.ptr(st.e), L.stream()))
@@ -577,11 +578,12 @@ class AREAD(HempMixin, nn.Module):
         table, gtable = (self.embedding.embedding_dict.weight, bufs["gtable"]) if l2_target is None else l2_target
         if masks_dev is None:
             masks_dev = self._masks_dev(self.domain_mask, x.device)
-        if plan is None:
-            plan = RowPlan(x, self.domain_idx if n_seg > 1 else -1, n_seg)
         main, side = torch.cuda.current_stream(), self._side_stream(x.device)
         part = self._l2_partials(x.device)
         self.embedding._ws_for(x)                      # allocate on the main stream's pool before forking
+        # Host issue order matters (eager launches): the table L2 pass needs nothing from this batch and goes first on
+        # the side stream; then the main stream gets its whole forward; only then the index sort (which needs the row
+        # plan, not the forward) is queued on the side stream, so the main stream never waits for the host.
         side.wait_stream(main)
         with torch.cuda.stream(side):
             if not table_pass:
@@ -594,12 +596,19 @@ class AREAD(HempMixin, nn.Module):
             else:
                 gtable.zero_()
                 bufs["reg"].zero_()
-            if presort:
-                self.embedding.sort_lookups(x, plan.sample_row)
+        if plan is None:
+            plan = RowPlan(x, self.domain_idx if n_seg > 1 else -1, n_seg)
+        if presort:
+            plan_ready = torch.cuda.Event()
+            plan_ready.record(main)
         st, gate = self._run(x, 0, n_seg, domain_i, masks_dev, want_gates, y=y, seg_weight=seg_weight,
                              loss_out=bufs["loss"], ws=bufs["ws"], probs=bufs["probs"], e=bufs["e"], plan=plan,
-                             e_ready=e_ready)
-        st.call.async_tail = 1          # parameter gradients finish on the library's side stream: see step_finish
+                             e_ready=e_ready, async_fwd=True)
+        if presort:
+            side.wait_event(plan_ready)
+            with torch.cuda.stream(side):
+                self.embedding.sort_lookups(x, plan.sample_row)
+        st.call.async_tail = 3          # parameter gradients finish on the library's side stream: see step_finish
         L.check(lib.aread_backward(self._handle, C.byref(st.call), L.ptr(st.e), None, L.ptr(bufs["gdense"]),
                                    L.ptr(bufs["de"]), L.stream()))
         st.call.async_tail = 0

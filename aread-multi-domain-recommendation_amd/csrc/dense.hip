@@ -247,7 +247,9 @@ extern "C" int aread_forward(const aread_model* m, const aread_call* c, const fl
         hipLaunchKernelGGL(k_bn_running, dim3(cdiv(max_cols, 256), all.n_layers), dim3(256), 0, x.side, all);
         AR_LAUNCH_CHECK();
     }
-    if (side_tail) TRY(join_side(x));
+    // async_tail bit 1: loss_out / running statistics finish on the side stream (fused step: the backward that follows
+    // does not read them and queues its own side-stream work behind them; aread_join() covers both)
+    if (side_tail && !(c->async_tail & 2)) TRY(join_side(x));
     return AREAD_OK;
 }
 
@@ -465,6 +467,9 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
         LAUNCH(k_reduce_tiles, dim3(cdiv(m->gate_rows, 32)), dim3(256), ws + x.w.misc_part, (int64_t)1024, m->gate_rows,
                grads + m->tgate_b, m->gate_rows, (int64_t)0, 0, 1, x.r);
     }
+    // every weight-gradient GEMM and bias partial is queued: their batched reductions follow on the side stream
+    // now, concurrently with the row-wise backward on the main stream (they do not depend on it)
+    TRY(flush_reductions(x));
     x.st = main_st;
     // 7. row-wise trunk backward (adds into de_out): the end of the critical path; needs dq and deg from the side stream
     AR_HIP(hipStreamWaitEvent(x.st, ev_gates, 0));
@@ -491,11 +496,10 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
            (int64_t)0, 0, SUB, x.r);
     LAUNCH(k_seg_reduce, dim3(c->n_seg, cdiv(E, 16)), dim3(256), ws + x.w.dgrp_part, (int64_t)E, E, ws + x.w.grp, SUB, x.r);
     LAUNCH(k_grp_bwd, dim3(1), dim3(256), ws + x.w.grp, grads + m->group_emb, cfg.n_tower[0], E, x.r, x.mp);
-    TRY(flush_reductions(x));
     x.st = main_st;
     // de_out is complete on the main stream here; the parameter gradients complete on the side stream.
     // async_tail: the caller overlaps its own work (embedding scatter) and calls aread_join() afterwards.
-    if (!c->async_tail) TRY(join_side(x));
+    if (!(c->async_tail & 1)) TRY(join_side(x));
     return AREAD_OK;
 }
 

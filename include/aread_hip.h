@@ -220,9 +220,12 @@ typedef struct aread_call {
     const float* y;           /* optional labels [B] (float 0/1): enables the fused loss + its gradient */
     const float* seg_weight;  /* optional [n_seg] weights w_d of the per-domain bagging losses (default 1) */
     float* loss_out;          /* optional out: [1 + n_seg]: sum_d w_d*bag_d, then bag_d per segment */
-    int32_t async_tail;       /* aread_backward: 1 = return with de_out complete on `stream` but the parameter
+    int32_t async_tail;       /* bit 0 (aread_backward): return with de_out complete on `stream` but the parameter
                                  gradients still finishing on the model's internal side stream; the caller overlaps
-                                 its own work and then calls aread_join(m, stream) */
+                                 its own work and then calls aread_join(m, stream).
+                                 bit 1 (aread_forward): return with probs complete on `stream` but loss_out and the
+                                 running statistics still finishing on the side stream (a following aread_backward
+                                 queues behind them; aread_join covers both) */
 } aread_call;
 
 /* e_in: embedding output in plan order [plan.max_rows][D] (aread_embed_fwd with the plan's row_sample). */

@@ -144,8 +144,11 @@ def test_fused_training_step_matches_train_step_plus_torch_adam():
     np.testing.assert_allclose(losses[0], ref_losses[0], rtol=1e-6)
     np.testing.assert_allclose(losses, ref_losses, rtol=2e-4)          # later steps: see the dense tolerance below
     wa, wb = a.embedding.embedding_dict.weight.data, b.embedding.embedding_dict.weight.data
-    # every element moved by ~lr per step; both paths must agree far inside that
-    assert float((wa - wb).abs().max()) <= 3e-5 and float((wa - wb).abs().mean()) <= 1e-7
+    # every element moved by ~lr per step; both paths must agree far inside that.  Isolated entries of hot rows whose
+    # ~B/10 contributions cancel to |g| ~ 1e-9 are renormalised by Adam, so the two summation orders (L2 term first vs
+    # last) can differ there by a fraction of one lr step: bound the count of such entries, not only the maximum
+    dw = (wa - wb).abs()
+    assert float(dw.max()) <= 3e-4 and float(dw.mean()) <= 1e-6 and int((dw > 1e-5).sum()) <= max(20, dw.numel() // 10000)
     assert float((wb - U.build_model(spec, seed)[0].embedding.embedding_dict.weight.data).abs().max()) > 2e-3
     # dense: the bias of a Linear that feeds BatchNorm has a zero true gradient; what is computed is rounding noise
     # (~1e-10..1e-7) that Adam renormalises to up to +-lr per step and that decorrelates between any two
