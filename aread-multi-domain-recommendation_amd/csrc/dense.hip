@@ -443,13 +443,8 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     // the row-wise backward only needs the side stream up to here (dq, deg), not the weight-gradient GEMMs behind it
     hipEvent_t ev_gates = x.m->ev[x.ev_next++ % (x.m->n_ev - 1)];
     AR_HIP(hipEventRecord(ev_gates, x.side));
-    // 5. experts; the first layer writes de_out
-    for (int j = nle - 1; j >= 0; --j) {
-        const float* in = j == 0 ? e_in : ws + x.w.ex[j - 1].Act;
-        float* d_in = j == 0 ? de_out : ws + x.w.ex[j - 1].dAct;
-        TRY(layer_bwd(x, m->experts.L[j], x.w.ex[j], in, d_in, 0, grads, -1, x.w.slab_ex[j]));
-    }
-    // 6. gate weight / bias gradients (side stream)
+    // 4b. gate weight / bias gradients (side stream): they only need dglogE / dglogT, so they are queued BEFORE the
+    // big expert weight gradients instead of lengthening the side stream's tail after them
     const int n_ge = cfg.n_tower[0] * cfg.n_expert;
     const hipStream_t main_st = x.st;
     TRY(wgrad(x, ws + x.w.dglogE, m->ld_ge, 0, e_in, D, 0, 1, n_ge, D, grads + m->gate_w, D, 0, nullptr, x.w.slab_gate));
@@ -467,8 +462,17 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
         LAUNCH(k_reduce_tiles, dim3(cdiv(m->gate_rows, 32)), dim3(256), ws + x.w.misc_part, (int64_t)1024, m->gate_rows,
                grads + m->tgate_b, m->gate_rows, (int64_t)0, 0, 1, x.r);
     }
+    x.st = main_st;
+    // 5. experts; the first layer writes de_out
+    for (int j = nle - 1; j >= 0; --j) {
+        const float* in = j == 0 ? e_in : ws + x.w.ex[j - 1].Act;
+        float* d_in = j == 0 ? de_out : ws + x.w.ex[j - 1].dAct;
+        TRY(layer_bwd(x, m->experts.L[j], x.w.ex[j], in, d_in, 0, grads, -1, x.w.slab_ex[j]));
+    }
     // every weight-gradient GEMM and bias partial is queued: their batched reductions follow on the side stream
     // now, concurrently with the row-wise backward on the main stream (they do not depend on it)
+    TRY(fork_side(x));
+    x.st = x.side;
     TRY(flush_reductions(x));
     x.st = main_st;
     // 7. row-wise trunk backward (adds into de_out): the end of the critical path; needs dq and deg from the side stream
@@ -483,17 +487,20 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     // 8. everything that only finishes parameter gradients runs on the side stream
     TRY(fork_side(x));
     x.st = x.side;
-    const float* rp = ws + x.w.rw_part;
-    if (cfg.n_cross > 0) {
-        LAUNCH(k_reduce_tiles, dim3(cdiv(cfg.n_cross * D, 32)), dim3(256), rp, rb.part_ld, cfg.n_cross * D, grads + m->cn_w,
-               cfg.n_cross * D, (int64_t)0, 0, SUB, x.r);
-        LAUNCH(k_reduce_tiles, dim3(cdiv(cfg.n_cross * D, 32)), dim3(256), rp + (int64_t)cfg.n_cross * D, rb.part_ld, cfg.n_cross * D,
-               grads + m->cn_b, cfg.n_cross * D, (int64_t)0, 0, SUB, x.r);
+    {
+        ReduceMultiP rm = {};
+        rm.part = ws + x.w.rw_part; rm.ld = rb.part_ld; rm.sub = SUB; rm.r = x.r;
+        int c = 0;
+        auto range = [&](int n, float* out) {
+            if (n <= 0) return;
+            rm.c0[rm.n] = c; rm.c1[rm.n] = c + n; rm.out[rm.n] = out; ++rm.n; c += n;
+        };
+        range(cfg.n_cross * D, grads + m->cn_w);       // partial layout: [cn_w | cn_b | lin_w | lin_b] (k_rowwise_bwd)
+        range(cfg.n_cross * D, grads + m->cn_b);
+        range(D, grads + m->lin_w);
+        range(1, grads + m->lin_b);
+        LAUNCH(k_reduce_tiles_multi, dim3(cdiv(c, 32)), dim3(256), rm);
     }
-    LAUNCH(k_reduce_tiles, dim3(cdiv(D, 32)), dim3(256), rp + (int64_t)2 * cfg.n_cross * D, rb.part_ld, D, grads + m->lin_w, D,
-           (int64_t)0, 0, SUB, x.r);
-    LAUNCH(k_reduce_tiles, dim3(1), dim3(256), rp + (int64_t)(2 * cfg.n_cross + 1) * D, rb.part_ld, 1, grads + m->lin_b, 1,
-           (int64_t)0, 0, SUB, x.r);
     LAUNCH(k_seg_reduce, dim3(c->n_seg, cdiv(E, 16)), dim3(256), ws + x.w.dgrp_part, (int64_t)E, E, ws + x.w.grp, SUB, x.r);
     LAUNCH(k_grp_bwd, dim3(1), dim3(256), ws + x.w.grp, grads + m->group_emb, cfg.n_tower[0], E, x.r, x.mp);
     x.st = main_st;

@@ -32,6 +32,36 @@ __global__ __launch_bounds__(256) void k_reduce_tiles(const float* part, int64_t
     }
 }
 
+// The same reduction for up to 4 column ranges of one partial buffer with separate destinations, in one launch
+// (the row-wise backward's cn_w / cn_b / lin_w / lin_b partials): column c of range j goes to out[j][c - c0[j]].
+struct ReduceMultiP {
+    const float* part; int64_t ld; int n, sub;
+    int c0[4], c1[4]; float* out[4];
+    RowsP r;
+};
+__global__ __launch_bounds__(256) void k_reduce_tiles_multi(const ReduceMultiP p) {
+    __shared__ float s_acc[8][33];
+    const int cl = threadIdx.x & 31, tg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    const int ncols = p.c1[p.n - 1];
+    float s = 0.f;
+    if (c < ncols) {
+        const int n_slots = p.r.hdr[PLAN_NTILES] * p.sub;
+#pragma unroll 8
+        for (int t = tg; t < n_slots; t += 8) s += p.part[(int64_t)t * p.ld + c];
+    }
+    s_acc[tg][cl] = s;
+    __syncthreads();
+    if (tg == 0 && c < ncols) {
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tot += s_acc[k][cl];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < p.n && c >= p.c0[j] && c < p.c1[j]) p.out[j][c - p.c0[j]] = tot;
+    }
+}
+
 // out[seg][c] = sum over the tiles of segment seg of part[tile*ld + c]   (grid: (n_seg, ceil(ncols/16)))
 __global__ __launch_bounds__(256) void k_seg_reduce(const float* part, int64_t ld, int ncols, float* out, int sub, RowsP r) {
     __shared__ float s_acc[16][17];

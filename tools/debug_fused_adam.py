@@ -29,6 +29,9 @@ for rep in range(4):
     wa, wb = a.embedding.embedding_dict.weight.data, b.embedding.embedding_dict.weight.data
     d = (wa - wb).abs()
     i = int(d.argmax()) // wa.shape[1]
-    res.append((wa.clone(), wb.clone()))
+    res.append((wa.clone(), wb.clone(), a.dense.data.clone(), b.dense.data.clone()))
+    dd = (a.dense.data - b.dense.data).abs()
+    print("   dense max %.3e mean %.3e n>5e-5: %d" % (float(dd.max()), float(dd.mean()), int((dd > 5e-5).sum())))
     print(rep, float(d.max()), float(d.mean()), "row", i, "n>1e-5:", int((d > 1e-5).sum()))
-print("a reproducible:", all(torch.equal(res[0][0], r[0]) for r in res), " b reproducible:", all(torch.equal(res[0][1], r[1]) for r in res))
+print("a reproducible:", all(torch.equal(res[0][0], r[0]) and torch.equal(res[0][2], r[2]) for r in res),
+      " b reproducible:", all(torch.equal(res[0][1], r[1]) and torch.equal(res[0][3], r[3]) for r in res))
