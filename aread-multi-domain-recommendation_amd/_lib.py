@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaread_hip.so")
+LIB_PATH = os.environ.get("AREAD_HIP_LIB") or os.path.join(_HERE, "libaread_hip.so")   # env override: A/B builds
 _lib = None
 
 i32p, f32p, vp = C.c_void_p, C.c_void_p, C.c_void_p   # device pointers travel as integers

@@ -151,13 +151,14 @@ extern "C" int aread_forward(const aread_model* m, const aread_call* c, const fl
     mp.group_emb = P + m->group_emb;
     mp.active = (uint8_t*)(ws + x.w.active); mp.kact = (int32_t*)(ws + x.w.kact); mp.n0act = mp.kact + MAX_SEG;
     mp.seg_dom = (int32_t*)(ws + x.w.seg_dom); mp.grp = ws + x.w.grp;
-    LAUNCH(k_mask_prep, dim3(1), dim3(256), mp);
-    if (c->probs) AR_HIP(hipMemsetAsync(c->probs, 0, (size_t)m->n_heads * c->B * sizeof(float), x.st));
-    // 2.+3. (side stream, joined before the MMoE mix) row-wise trunk, gate logits, cross-network part of the heads
+    // 1.-3. (side stream, joined before the MMoE mix: the expert layers need none of it) mask tables, row-wise trunk,
+    // gate logits, cross-network part of the heads
     TRY(fork_side(x));
     {
         const hipStream_t main_st = x.st;
         x.st = x.side;
+        LAUNCH(k_mask_prep, dim3(1), dim3(256), mp);
+        if (c->probs) AR_HIP(hipMemsetAsync(c->probs, 0, (size_t)m->n_heads * c->B * sizeof(float), x.st));
         if (c->train && cfg.precision == 1) {          // transposed weights for the split-bf16 dgrad of the backward
             TransAllP ta = {};
             int64_t mx = 0;

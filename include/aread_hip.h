@@ -50,11 +50,12 @@ const char* aread_last_error(void);
  * Replaces: the per-domain DataLoaders + Python loop over domains (run.py:310-353, 609-611) and the
  * host-side `if not this_level_active_tower[t]` branches (aread.py:272,309,320).
  *
- * Plan buffer layout (int32 words), sized by aread_plan_words(B, n_seg):
+ * Plan buffer layout (int32 words), sized by aread_plan_layout_get(B, n_seg).words:
  *   [0] B  [1] n_seg  [2] rows_padded (device-computed)  [3] n_tiles (device-computed)  [4..15] reserved
  *   seg_count[AREAD_MAX_SEG]  seg_start[AREAD_MAX_SEG]      (start row, tile aligned)
  *   tile_seg[max_tiles]  (-1 = unused tile)   tile_valid[max_tiles] (valid rows in the tile)
  *   row_sample[max_rows] (sample index of a padded row, -1 = padding)   sample_row[B]
+ *   scratch of aread_plan_build (per-wave segment counts), not part of the contract
  * max_rows (aread_plan_layout.max_rows) is the host-known upper bound used for grid sizes.
  * ------------------------------------------------------------------------------------------- */
 typedef struct aread_plan_layout {   /* host-side description of the plan buffer (int32 word offsets) */
