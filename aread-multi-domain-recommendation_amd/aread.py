@@ -639,8 +639,14 @@ class AREAD(HempMixin, nn.Module):
         besides the row plan (run.py:668-680 without the optimizer).  y: float32 [B] on the device.
         Returns the device scalar loss = sum_d w_d*bag_d + reg."""
         st = self.step_local(x, y, bufs, masks_dev, domain_i, seg_weight, with_reg, True, want_gates, presort=True)
-        self.embedding.reduce_sorted(x, bufs["de"], bufs["gtable"])      # overlaps the tail reductions of the backward
-        self.step_finish(bufs)
+        # tail: the segmented reduction into the table gradient on the main stream, concurrently (side stream) the join
+        # with the library's parameter-gradient reductions and the dense L2 term
+        main, side = torch.cuda.current_stream(), self._side_stream(x.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self.step_finish(bufs)
+        self.embedding.reduce_sorted(x, bufs["de"], bufs["gtable"])
+        main.wait_stream(side)
         torch.add(bufs["loss"][:1], bufs["reg"][:1], out=bufs["total"])
         if set_grads:
             for p in self.dense_params:
