@@ -43,6 +43,8 @@ def parse():
                     help="GEMM arithmetic of the expert/tower forward+dgrad: exact fp32 MFMA or split-bf16 (3 products)")
     ap.add_argument("--step-only", action="store_true", help="profiling: run only the warm-up + timed steps (no roofline "
                     "micro-loops, no forward-only / fused-optimizer extras, no CPU baseline), so rocprofv3 sees the pure step")
+    ap.add_argument("--kernels-only", action="store_true", help="profiling: one step to size the buffers, then only the "
+                    "isolated roofline kernel loops (so a rocprofv3 --stats average is the isolated launch duration)")
     ap.add_argument("--force-dp", action="store_true", help="use the multi-GPU code path even with one rank (testing)")
     ap.add_argument("--table", default="auto", choices=["auto", "replicated", "sharded"],
                     help="multi-GPU embedding table: replicated (all_gather of ids/dE) or row-sharded (all_to_all lookup, "
@@ -200,6 +202,15 @@ def main():
         dp_state["times_ms"] = {k: round(v * 1e3, 4) for k, v in times.items()}
         log(f"table variant: {dp_state['times_ms']} -> {dp_state['variant']}")
 
+    if args.kernels_only:
+        res = {"gemm_roofline": measure_gemm_kernel(model, bufs, L, B, args.precision),
+               "wgrad_roofline": measure_wgrad_kernel(model, bufs, L, B), "l2_table_roofline": measure_l2_kernel(model, bufs, L),
+               "gather_roofline": measure_gather_kernel(model, xs, bufs, L), "note": "--kernels-only profiling run"}
+        if rank == 0:
+            os.write(json_fd, (json.dumps(res) + "\n").encode())
+        if use_dp:
+            dist.destroy_process_group()
+        return
     for i in range(args.warmup):
         run_one(i)
     torch.cuda.synchronize()
