@@ -297,8 +297,9 @@ class AREAD(HempMixin, nn.Module):
         else:
             act = [[False] * n for n in self.n_tower]
             for mk in masks:
-                if mk is None:
-                    continue
+                if mk is None:                       # no mask installed for this domain: treat every tower as reachable
+                    act = [[True] * n for n in self.n_tower]
+                    break
                 for l in range(self.n_level):
                     a = np.asarray(mk[l].cpu() if isinstance(mk[l], torch.Tensor) else mk[l]).any(axis=0)
                     for t in range(self.n_tower[l]):
