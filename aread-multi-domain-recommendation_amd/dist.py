@@ -114,13 +114,19 @@ class DataParallelStep:
             x_all, sr_all = gather_ids(x, plan.sample_row, plan.max_rows, self.group)
             m.embedding.sort_lookups(x_all, sr_all)
             x_all.record_stream(side2); sr_all.record_stream(side2)
+            sorted_ev = torch.cuda.Event()
+            sorted_ev.record(side2)
         st = m.step_local(x, y, b, masks_dev=masks_dev, with_dense_l2=False, presort=False, plan=plan)
         de_all = gather_rows(b["de"], self.group)
-        m.step_finish(b)
-        reduce_dense_grad(b["gdense"], self.group)
-        m.add_dense_l2(b)
-        main.wait_stream(side2)
+        # dense gradients (join, all_reduce, L2) on the side stream, concurrently with the global table reduction
+        side2.wait_stream(main)
+        with torch.cuda.stream(side2):
+            m.step_finish(b)
+            reduce_dense_grad(b["gdense"], self.group)
+            m.add_dense_l2(b)
+        main.wait_event(sorted_ev)                                   # global lookups sorted
         m.embedding.reduce_sorted(x_all, de_all, b["gtable"])
+        main.wait_stream(side2)
         torch.add(b["loss"][:1], b["reg"][:1], out=b["total"])
         self._keep = (x_all, sr_all, de_all, st)
         return b["total"]
