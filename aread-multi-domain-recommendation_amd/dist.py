@@ -330,6 +330,7 @@ class ShardedTableStep:
         n = model.dense.numel()
         self.chunk = (n + self.P - 1) // self.P
         self.gpad = torch.zeros(self.chunk * self.P, dtype=torch.float32, device=dev)
+        self.bufs["gdense"] = self.gpad[:n]                           # the backward writes straight into the padded buffer
         self.dense_pad = torch.zeros(self.chunk * self.P, dtype=torch.float32, device=dev)
         self.dense_pad[:n].copy_(model.dense.data)
         self.coef_pad = torch.zeros(self.chunk * self.P, dtype=torch.float32, device=dev)
@@ -395,6 +396,8 @@ class ShardedTableStep:
             if n:
                 L.check(lib.aread_embed_bwd_sort(L.ptr(route.recv_rows), n, 1, L.ptr(self._zero1), self.shard.shape[0],
                                                  emb.embed_dim, 1, 0, 1, 0, None, L.ptr(ws_o), L.stream()))
+            self._sorted_ev = torch.cuda.Event()
+            self._sorted_ev.record(self._side)
 
     def table_grad(self, x, route, plan):
         """bufs['de'] -> self.gshard (+= on top of the shard's L2 gradient); presort() must have run"""
@@ -403,7 +406,7 @@ class ShardedTableStep:
         B, f_in = x.shape
         seq = emb.seq_maxlen if emb._pool != 0 else 1
         g_unique = torch.zeros((route.n_unique, emb.embed_dim), dtype=torch.float32, device=x.device)
-        torch.cuda.current_stream().wait_stream(self._side)
+        torch.cuda.current_stream().wait_event(self._sorted_ev)     # both index sorts (presort) are done
         L.check(lib.aread_embed_bwd_reduce(B, f_in, emb.embed_dim, seq, L.ptr(b["de"]), L.ptr(g_unique),
                                            L.ptr(self._bwd_ws("u", B, f_in)), L.stream()))
         g_recv = self.router.push(route, g_unique)
@@ -421,16 +424,21 @@ class ShardedTableStep:
         self.presort(x, route, plan)
         st = m.step_local(x, y, b, masks_dev=masks_dev, with_dense_l2=False, presort=False, plan=plan, e_ready=True,
                           l2_target=(self.shard.data, self.gshard))
-        self.table_grad(x, route, plan)
-        m.step_finish(b)                                               # dense gradients of the local batch complete
-        n = m.dense.numel()
-        self.gpad[:n].copy_(b["gdense"])
-        reduce_scatter_flat(self.gchunk, self.gpad, self.group)
+        # dense gradients (join, reduce_scatter, dense L2 on the owned chunk, reg all_reduce) on the side stream,
+        # concurrently with the table-gradient exchange on the main stream
+        main, side = torch.cuda.current_stream(), self._side
         lo = self.p * self.chunk
-        self.reg.copy_(b["reg"])                                       # table L2 of this shard
-        L.check(lib.aread_l2_dense(L.ptr(self.dense_chunk.data), L.ptr(self.coef_pad[lo:lo + self.chunk]), self.chunk,
-                                   L.ptr(self.gchunk), L.ptr(self.reg), 1, L.stream()))
-        reg = all_reduce_any(self.reg[:1].clone(), self.group)         # reg = sum over shards / chunks
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            m.step_finish(b)                                           # dense gradients of the local batch complete
+            reduce_scatter_flat(self.gchunk, self.gpad, self.group)    # bufs['gdense'] is a view of gpad
+            self.reg.copy_(b["reg"])                                   # table L2 of this shard
+            L.check(lib.aread_l2_dense(L.ptr(self.dense_chunk.data), L.ptr(self.coef_pad[lo:lo + self.chunk]), self.chunk,
+                                       L.ptr(self.gchunk), L.ptr(self.reg), 1, L.stream()))
+            reg = all_reduce_any(self.reg[:1].clone(), self.group)     # reg = sum over shards / chunks
+            reg.record_stream(side)
+        self.table_grad(x, route, plan)
+        main.wait_stream(side)
         torch.add(b["loss"][:1], reg, out=self.total)
         self._keep = (route, urows, st, plan)
         return self.total
