@@ -193,11 +193,19 @@ def main():
         times = {}
         for name in variants:
             dp_state["variant"] = name
-            quick(3)
-            dist.barrier()
-            tt = torch.tensor([quick()], device=dev, dtype=torch.float64)
+            try:                                     # a variant that fails the same way on every rank is skipped, not fatal
+                quick(3)
+                dist.barrier()
+                t_var, failed = quick(), 0.0
+            except Exception as exc:                 # noqa: BLE001
+                log(f"table variant {name} failed: {type(exc).__name__}: {exc}")
+                t_var, failed = 1e9, 1.0
+            tt = torch.tensor([t_var, failed], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            times[name] = float(tt[0])
+            if float(tt[1]) == 0.0:
+                times[name] = float(tt[0])
+        if not times:
+            raise RuntimeError("no multi-GPU table variant ran")
         dp_state["variant"] = min(times, key=times.get)
         dp_state["times_ms"] = {k: round(v * 1e3, 4) for k, v in times.items()}
         log(f"table variant: {dp_state['times_ms']} -> {dp_state['variant']}")
