@@ -166,3 +166,37 @@ def test_fused_training_step_matches_train_step_plus_torch_adam():
         if not on:
             n = int(np.prod(shape)) if shape else 1
             assert float(fused.m_dense[off:off + n].abs().max()) == 0.0
+
+
+def test_fused_step_accepts_a_smaller_last_batch():
+    """buffers sized for B = 512 drive a 300-row batch (the last batch of an epoch) to exactly the same update as buffers
+    sized for 300, and a full-size step still works afterwards"""
+    import aread_amd
+    fn, mk, seed = U.GOLDEN_MODELS["full"]
+    G, spec = U.load_golden(fn), mk()
+    masks = U.golden_masks(spec, G, "rand")
+    x = torch.from_numpy(G["multi_rand/x"]).cuda()
+    y = torch.from_numpy(G["multi_rand/y"].astype(np.float32)).cuda()
+    n_small = min(300, x.shape[0] - 1)
+    xs, ys = x[:n_small].contiguous(), y[:n_small].contiguous()
+    rep = (512 + x.shape[0] - 1) // x.shape[0]
+    xb, yb = x.repeat(rep, 1)[:512].contiguous(), y.repeat(rep)[:512].contiguous()
+
+    def run(cap, then_full):
+        model, _ = U.build_model(spec, seed, dropout=0.2)
+        model.train()
+        model.drop_seed = 5
+        model.domain_mask = [[torch.tensor(np.asarray(m), dtype=torch.bool, device="cuda") for m in mk_] for mk_ in masks]
+        md = aread_amd.pack_masks(masks, spec.n_domain, model.edge_num, "cuda")
+        fused = aread_amd.FusedAdam(model, cap, **HYPER)
+        loss = float(fused.step(xs, ys, md))
+        state = (model.embedding.embedding_dict.weight.data.clone(), model.dense.data.clone())
+        if then_full:
+            assert np.isfinite(float(fused.step(xb, yb, md)))
+        torch.cuda.synchronize()
+        return loss, state
+
+    loss_big, (w_big, d_big) = run(512, then_full=True)
+    loss_small, (w_small, d_small) = run(n_small, then_full=False)
+    assert loss_big == loss_small
+    assert torch.equal(w_big, w_small) and torch.equal(d_big, d_small)
