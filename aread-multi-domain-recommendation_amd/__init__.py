@@ -7,6 +7,6 @@ from .layer import FeaturesEmbedding, MultiLayerPerceptron   # noqa: F401
 from .plan import RowPlan                           # noqa: F401
 from .aread import AREAD, pack_masks                # noqa: F401
 from . import dist                                  # noqa: F401
-from .optim import FusedAdam                        # noqa: F401
+from .optim import FusedAdam, Adam                  # noqa: F401
 
-__all__ = ["FeaturesEmbedding", "MultiLayerPerceptron", "RowPlan", "AREAD", "pack_masks", "FusedAdam"]
+__all__ = ["FeaturesEmbedding", "MultiLayerPerceptron", "RowPlan", "AREAD", "pack_masks", "FusedAdam", "Adam"]

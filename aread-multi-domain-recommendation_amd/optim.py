@@ -132,3 +132,72 @@ class FusedAdam:
             L.check(lib.aread_adam_step(L.ptr(m.dense), L.ptr(b["gdense"]), L.ptr(self.m_dense), L.ptr(self.v_dense),
                                         m.dense.numel(), L.ptr(act), C.byref(cfg), L.stream()))
         return self.total
+
+
+class Adam(torch.optim.Optimizer):
+    """Drop-in for `torch.optim.Adam(model.parameters(), lr, betas, eps, weight_decay)` in the reference's step loop
+    (run.py:830-831, 680-681): the same update, but the 178 MB table and the flat dense buffer take ONE kernel launch each
+    instead of ~300 per-tensor launch groups.  Construct it with the MODEL (it needs to know that the dense parameters are
+    views of one buffer); `zero_grad` / `step` / `state_dict` behave as usual.  Tensors whose grad is None are skipped
+    exactly as torch does (no decay, no moment update, no step count)."""
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.0):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(list(model.parameters()), defaults)
+        self.model = model
+        self._t_table = 0
+        self._t_dense = np.zeros(len(model._ptensors), dtype=np.int64)
+        self._m_table = self._v_table = self._m_dense = self._v_dense = None
+        self._active = {}
+
+    def _cfg(self, step):
+        g = self.param_groups[0]
+        c = AdamCfg()
+        c.lr, c.beta1, c.beta2, c.eps, c.weight_decay = g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"]
+        c.step = int(step)
+        return c
+
+    def _active_mask(self, sel):
+        key = sel.tobytes()
+        if key not in self._active:
+            m = self.model
+            a = np.zeros(m.dense.numel(), dtype=np.uint8)
+            for on, (name, kind, off, shape, l2) in zip(sel, m._ptensors):
+                if on:
+                    a[off:off + (int(np.prod(shape)) if shape else 1)] = 1
+            self._active[key] = torch.from_numpy(a).to(m.dense.device)
+        return self._active[key]
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        m = self.model
+        lib = L.lib()
+        table = m.embedding.embedding_dict.weight
+        if table.grad is not None:
+            if self._m_table is None:
+                self._m_table, self._v_table = torch.zeros_like(table.data), torch.zeros_like(table.data)
+            g = table.grad.contiguous()
+            self._t_table += 1
+            cfg = self._cfg(self._t_table)
+            L.check(lib.aread_adam_step(L.ptr(table.data), L.ptr(g), L.ptr(self._m_table), L.ptr(self._v_table), table.numel(),
+                                        None, C.byref(cfg), L.stream()))
+        present = np.array([p.grad is not None for p in m.dense_params], dtype=bool)
+        if present.any():
+            if self._m_dense is None:
+                self._m_dense, self._v_dense = torch.zeros_like(m.dense), torch.zeros_like(m.dense)
+            gflat = m._gflat                                   # every present .grad is a view of this flat buffer
+            k = int(np.argmax(present))
+            if gflat is None or m.dense_params[k].grad.data_ptr() != gflat.data_ptr() + 4 * m._ptensors[k][2]:
+                raise RuntimeError("aread_amd.Adam: dense gradients must come from this module's backward (views of one buffer)")
+            self._t_dense[present] += 1
+            for t in np.unique(self._t_dense[present]):
+                sel = present & (self._t_dense == t)
+                act = None if sel.all() else self._active_mask(sel)
+                cfg = self._cfg(t)
+                L.check(lib.aread_adam_step(L.ptr(m.dense), L.ptr(gflat), L.ptr(self._m_dense), L.ptr(self._v_dense),
+                                            m.dense.numel(), L.ptr(act), C.byref(cfg), L.stream()))
+        return loss

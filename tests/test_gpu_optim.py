@@ -200,3 +200,52 @@ def test_fused_step_accepts_a_smaller_last_batch():
     loss_small, (w_small, d_small) = run(n_small, then_full=False)
     assert loss_big == loss_small
     assert torch.equal(w_big, w_small) and torch.equal(d_big, d_small)
+
+
+def test_dropin_adam_matches_torch_adam_on_the_reference_step_loop():
+    """aread_amd.Adam(model) in place of torch.optim.Adam(model.parameters()) in the reference's per-domain step closure
+    (run.py:668-681): three steps with different masks (so some towers keep grad=None on some steps and their step counts
+    differ), table and dense parameters compared."""
+    import aread_amd
+    from tests.test_gpu_aread import tmask
+    fn, mk, seed = U.GOLDEN_MODELS["full"]
+    G, spec = U.load_golden(fn), mk()
+    crit = torch.nn.BCELoss()
+    hyper = dict(lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-8)
+
+    def run(make_opt):
+        model, _ = U.build_model(spec, seed, dropout=0.0)
+        model.train()
+        opt = make_opt(model)
+        losses = []
+        for mname in ("sparse", "rand", "ones"):
+            p = f"single_{mname}"
+            d = int(G[f"{p}/domain"])
+            masks = U.golden_masks(spec, G, mname)
+            x = torch.from_numpy(G[f"{p}/x"]).cuda()
+            y = torch.from_numpy(G[f"{p}/y"].astype(np.float32)).cuda()
+            preds = model(x, mode="domain_mask_bagging", domain_i=d, current_mask=tmask(masks[d]))
+            loss = sum(crit(pr, y) for pr in preds.unbind(dim=0)) / preds.shape[0] + model.get_regularization_loss(device="cuda")
+            model.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        torch.cuda.synchronize()
+        return losses, model.embedding.embedding_dict.weight.data.clone(), model.dense.data.clone(), model, opt
+
+    l_ref, w_ref, d_ref, _, _ = run(lambda m: torch.optim.Adam(m.parameters(), **hyper))
+    l_new, w_new, d_new, model, opt = run(lambda m: aread_amd.Adam(m, **hyper))
+    np.testing.assert_allclose(l_new[0], l_ref[0], rtol=1e-6)
+    np.testing.assert_allclose(l_new, l_ref, rtol=1e-4)
+    dw = (w_new - w_ref).abs()
+    assert float(dw.max()) <= 3e-4 and float(dw.mean()) <= 1e-6
+    dd = (d_new - d_ref).abs()
+    assert float(dd.mean()) <= 2e-7 and int((dd > 5e-5).sum()) <= dd.numel() // 2000
+    assert len(set(opt._t_dense.tolist())) > 1                    # the masks really produced different step counts
+    # tensors that never got a gradient kept their initial value in both runs
+    init = U.build_model(spec, seed, dropout=0.0)[0].dense.data
+    never = opt._t_dense == 0
+    for on, (name, kind, off, shape, l2) in zip(never, model._ptensors):
+        if on:
+            n = int(np.prod(shape)) if shape else 1
+            assert torch.equal(d_new[off:off + n], init[off:off + n]) and torch.equal(d_ref[off:off + n], init[off:off + n]), name

@@ -11,10 +11,12 @@ from tests.util import build_model
 spec = O.amazon_spec(dropout=0.2)
 rng = np.random.default_rng(0); mr = np.random.default_rng(2000)
 masks = [O.random_valid_mask(spec, mr, 0.7) for _ in range(25)]
-for precision in ("f32", "bf16x3"):
+import aread_amd
+for precision, opt_name in (("f32", "torch"), ("bf16x3", "torch"), ("bf16x3", "aread_amd.Adam")):
     model, P = build_model(spec, 123, precision=precision); model.train()
     model.domain_mask = [[torch.tensor(m, dtype=torch.bool, device="cuda") for m in mk] for mk in masks]
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-8)
+    hyper = dict(lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-8)
+    opt = torch.optim.Adam(model.parameters(), **hyper) if opt_name == "torch" else aread_amd.Adam(model, **hyper)
     crit = torch.nn.BCELoss()
     batches = []
     for d in (3, 6, 12):
@@ -33,7 +35,7 @@ for precision in ("f32", "bf16x3"):
     N = 30
     for i in range(N): l = train_step(i)
     float(l); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / N
-    print(f"[{precision}] drop-in train step (fwd + loss + bwd + Adam over table and {len(list(model.parameters()))} tensors): "
+    print(f"[{precision}, {opt_name}] drop-in train step (fwd + loss + bwd + Adam over table and {len(list(model.parameters()))} tensors): "
           f"{dt*1e3:.2f} ms/step = {8192/dt/1e6:.2f} M samples/s")
     model.eval()
     with torch.no_grad():
