@@ -171,3 +171,28 @@ def test_l2_table():
         ref = 1e-5 * float((w.astype(np.float64) ** 2).sum())
         assert abs(float(loss) - 3.0 - ref) < 1e-5 * max(ref, 1.0) + 2e-7 * 3.0
         np.testing.assert_allclose(grad.cpu().numpy(), 2e-5 * w, rtol=1e-6, atol=0)
+
+
+def test_embed_history_slots_without_pooling():
+    """multi_hot_dict['method'] = None with history columns present (layer.py:141-143,170-183): every slot keeps its own
+    output row, the slots share the itemid sub-table; forward bit-exact and backward vs torch index ops."""
+    import aread_amd
+    dims, E, S = [50, 4, 6], 16, 3
+    flag = [False] * 3 + [True] * (2 * S)
+    emb = aread_amd.FeaturesEmbedding(dims, E, {"multi_hot_flag": flag, "itemid_idx": 0, "seq_maxlen": S, "method": None}).cuda()
+    assert emb.output_dim0 == 3 + 2 * S
+    rng = np.random.default_rng(3)
+    B = 300
+    x = np.stack([rng.integers(0, d, B) for d in dims] + [rng.integers(0, dims[0] + 1, B) for _ in range(2 * S)], axis=1).astype(np.int32)
+    xd = torch.from_numpy(x).cuda()
+    out = emb(xd)
+    off = torch.from_numpy(emb.offsets.astype(np.int64)).cuda()
+    bag = xd.long() + off                                       # the pad id (= dims[0]) aliases row 0 of the next field
+    w = emb.embedding_dict.weight
+    assert tuple(out.shape) == (B, 9, E)
+    assert torch.equal(out, w.detach()[bag])
+    assert torch.equal(emb.index_bag(xd).long(), bag)
+    dout = torch.randn_like(out)
+    out.backward(dout)
+    ref = torch.zeros_like(w).index_put_((bag.reshape(-1),), dout.reshape(-1, E), accumulate=True)
+    torch.testing.assert_close(w.grad, ref, rtol=1e-5, atol=1e-6)
