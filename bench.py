@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="force hipGraph replay (default: time both briefly, keep the faster)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--workload", default="amazon", choices=["amazon", "aliccp"],
+                    help="amazon = the BASELINE metric's configuration (default); aliccp = BASELINE configs[4] layout: 23 "
+                         "one-hot fields, no history pooling, D = 736, 30 domains, 1.14 M-row table")
     ap.add_argument("--dropout", type=float, default=0.2)
     ap.add_argument("--domain-dist", default="proportional", choices=["proportional", "uniform"])
     ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3"],
@@ -87,7 +90,7 @@ def main():
     import aread_amd
     from aread_amd import _lib as L
 
-    spec = O.amazon_spec(dropout=args.dropout)
+    spec = O.amazon_spec(dropout=args.dropout) if args.workload == "amazon" else O.aliccp_spec(dropout=args.dropout)
     B = args.batch
     rng = np.random.default_rng(2000 + rank)
     mrng = np.random.default_rng(2000)
@@ -100,7 +103,11 @@ def main():
     n_batches = 4
     batches = []
     for _ in range(n_batches):
-        x, y = synth.amazon_batch(spec, rng, B, domain=args.domain_dist)
+        if args.workload == "amazon":
+            x, y = synth.amazon_batch(spec, rng, B, domain=args.domain_dist)
+        else:
+            x, y = synth.generic_batch(spec, rng, B, pos_rate=0.043,
+                                       domain_p=synth.ALICCP_DOMAIN_SIZE if args.domain_dist == "proportional" else None)
         batches.append((torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev), x, y))
     xs = torch.empty_like(batches[0][0])
     ys = torch.empty_like(batches[0][1])
@@ -261,13 +268,17 @@ def main():
     roofline = max((gemm, wgrad, l2pass), key=lambda r: r["avg_launch_us"])
 
     out = {
-        "metric": "CTR samples/s fwd+bwd, AREAD 25-domain batch=8192", "value": round(value, 1), "unit": "samples/s",
+        "metric": "CTR samples/s fwd+bwd, AREAD 25-domain batch=8192" if args.workload == "amazon"
+        else f"CTR samples/s fwd+bwd, AREAD 30-domain (AliCCP layout) batch={B}", "value": round(value, 1), "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if args.precision == "f32" else "bf16x3 (split-bf16 fwd/dgrad GEMMs, fp32 accumulate) + f32",
         "data": "synthetic",
-        "config": {"workload": "AREAD HEI+HEMP-mask fwd+bagging BCE+L2+bwd, Amazon-like 25-domain, dims "
-                               "[1368287,7,25,45,11,22356,10], E=32, 17 id columns, experts 4x(256,128,64), towers 3/6/12",
+        "config": {"workload": ("AREAD HEI+HEMP-mask fwd+bagging BCE+L2+bwd, Amazon-like 25-domain, dims "
+                                "[1368287,7,25,45,11,22356,10], E=32, 17 id columns, experts 4x(256,128,64), towers 3/6/12")
+                   if args.workload == "amazon" else
+                   ("AREAD HEI+HEMP-mask fwd+bagging BCE+L2+bwd, AliCCP-like 30-domain (BASELINE configs[4] layout), 23 one-hot "
+                    "fields, 1 140 414 table rows, E=32, D=736, experts 4x(256,128,64), towers 3/6/12"),
                    "batch_per_gpu": B, "global_batch": B * world, "domain_dist": args.domain_dist,
                    "dropout": args.dropout, "mask_active_frac": 0.7, "optimizer_in_timed_region": False,
                    "dense_table_l2_in_timed_region": True, "launch": "hipGraph replay" if graph is not None else "eager, fork-join side streams",
