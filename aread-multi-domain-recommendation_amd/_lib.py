@@ -44,6 +44,8 @@ _SIGS = {
     "aread_l2_finish": (C.c_int, [f32p, C.c_int, C.c_float, f32p, C.c_int, vp]),
     "aread_gemm_bf16x3": (C.c_int, [f32p, C.c_int64, C.c_int64, f32p, C.c_int64, C.c_int64, f32p, C.c_int64, C.c_int64, f32p,
                                     C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "aread_gemm_bf16x3_rc": (C.c_int, [f32p, C.c_int64, C.c_int64, f32p, C.c_int64, C.c_int64, f32p, C.c_int64, C.c_int64, C.c_int,
+                                       C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "aread_gemm": (C.c_int, [f32p, C.c_int64, C.c_int64, C.c_int, f32p, C.c_int64, C.c_int64, C.c_int, f32p, C.c_int64,
                              C.c_int64, f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
 }

@@ -273,7 +273,10 @@ static int wgrad(Ctx& x, const float* dY, int64_t ld_dy, int64_t dy_gs, const fl
     g.k_split = ks.k_split; g.k_chunk = ks.k_chunk;
     g.gate_axis = 2; g.tile_seg = x.r.tile_seg; g.tile_valid = x.r.tile_valid; g.active = active; g.active_ld = MAX_TOWER;
     TRY(fork_side(x));                                   // everything this wgrad reads has been issued on the main stream
-    TRY(launch_gemm(g, false, false, x.side));
+    // split-bf16 mode: the row-contiguous operands go through the transposing LDS reads (k_gemm_bf3_rc), 3 bf16 MFMA
+    // products instead of the fp32 MFMA -- 1.8x faster on the expert-L1 shape
+    if (x.m->cfg.precision == 1) TRY(launch_gemm_bf3_rc(g, x.side));
+    else TRY(launch_gemm(g, false, false, x.side));
     AR_CHECK_ARG(x.splitk.n < MAX_WGRADS, "too many wgrads");
     SplitKOne& d = x.splitk.d[x.splitk.n++];
     d.slab = x.ws + slab_off; d.out = out; d.k_split = ks.k_split; d.G = G; d.M = Mg; d.N = Ng; d.ldo = ldo; d.o_gs = o_gs;

@@ -466,6 +466,166 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm_bf3(const GemmP p) {
     gemm_epilogue<NI>(p, acc, g, 0, m0, n0, by, s_red, (float*)s_lds);
 }
 
+// ================================================================================================
+// split-bf16 kernel for ROW-contiguous operands (the weight gradients dW = dH^T X: K = the batch rows, element (r,k) at
+// base + k*ld + r for both operands).  The bf16 MFMA wants 8 consecutive k per lane, i.e. a transposed view of the
+// k-major tiles as they arrive from memory.  The tiles are staged as they are -- k-major [32 k][rows] bf16 images (hi and
+// lo), 8-byte stores of 4 consecutive rows -- and the fragments are read with ds_read_b64_tr_b16, which hands lane i of a
+// 16-lane group column i of a 4-row block: exactly (row i, 4 consecutive k).  Two such reads make one 8-k fragment.
+// LDS image (bank-conflict-free for the transposed reads, whose two 16-lane groups per half-wave touch k-rows 8g+4h+q
+// and 8(g+1)+4h+q, q = 0..3, at one 32-byte chunk of the row):
+//   rows <= 64 : k-rows r and r+8 share a 256-byte line (r+8 in the upper half), the 32-byte chunk index is XORed with r&3
+//   rows <= 128: one 256-byte line per k-row, chunk index XORed with (r&3) | ((r>>3)&1)<<2
+// so the eight 32-byte segments of a half-wave read land on eight different bank windows.
+// Same split-K geometry, k-tile gating (dead tiles hold stale data) and epilogue as k_gemm<NI,false,false>.
+// ================================================================================================
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+template <int ROWS>
+struct RcImage {
+    static constexpr bool WIDE = ROWS > 64;
+    static constexpr int ELEMS = (WIDE ? 32 : 16) * 128;                  // bf16 elements of one image (hi or lo)
+    static __device__ __forceinline__ int off(int r, int m) {            // element offset of (k-row r, row m of the operand)
+        const int c = m >> 4;
+        if (WIDE) return r * 128 + ((c ^ ((r & 3) | (((r >> 3) & 1) << 2))) << 4) + (m & 15);
+        return ((r & 7) | ((r >> 4) << 3)) * 128 + (((r >> 3) & 1) << 6) + ((c ^ (r & 3)) << 4) + (m & 15);
+    }
+};
+
+template <int ROWS>
+struct Bf3RcLoader {
+    static constexpr int Q = ROWS / 4;                                    // float4 per k-row
+    static constexpr int F4 = (Q * GEMM_BK + GEMM_THREADS - 1) / GEMM_THREADS;
+    float4 v[F4];
+
+    template <bool FULL>
+    __device__ __forceinline__ void load(const float* __restrict__ base, int64_t ld, int r0, int r_end, int k0, int k_end) {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int p = 0; p < F4; ++p) {
+            const int idx = tid + p * GEMM_THREADS;
+            const int krow = idx / Q, mq = idx - krow * Q;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((Q * GEMM_BK) % GEMM_THREADS == 0 || krow < GEMM_BK) {
+                const int k = k0 + krow, r = r0 + 4 * mq;
+                const float* ptr = base + (int64_t)k * ld + r;
+                if (FULL) t = *(const float4*)ptr;
+                else if (k < k_end) {
+                    if (r + 3 < r_end) t = *(const float4*)ptr;
+                    else {
+                        if (r < r_end) t.x = ptr[0];
+                        if (r + 1 < r_end) t.y = ptr[1];
+                        if (r + 2 < r_end) t.z = ptr[2];
+                    }
+                }
+            }
+            v[p] = t;
+        }
+    }
+
+    __device__ __forceinline__ void store(__bf16* __restrict__ hi, __bf16* __restrict__ lo) const {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int p = 0; p < F4; ++p) {
+            const int idx = tid + p * GEMM_THREADS;
+            const int krow = idx / Q, mq = idx - krow * Q;
+            if ((Q * GEMM_BK) % GEMM_THREADS == 0 || krow < GEMM_BK) {
+                const float x[4] = {v[p].x, v[p].y, v[p].z, v[p].w};
+                bf16x4 h, l;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    h[i] = (__bf16)x[i];
+                    l[i] = (__bf16)(x[i] - (float)h[i]);
+                }
+                const int o = RcImage<ROWS>::off(krow, 4 * mq);
+                *(bf16x4*)(hi + o) = h;
+                *(bf16x4*)(lo + o) = l;
+            }
+        }
+    }
+};
+
+// 8-k fragment of 16 rows starting at row m0 (a multiple of 16): two transposed reads (k = 8g .. 8g+3 and 8g+4 .. 8g+7)
+template <int ROWS>
+__device__ __forceinline__ bf16x8 rc_fragment(const __bf16* img, int m0, int lane) {
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    typedef __attribute__((address_space(3))) s16x4* lds_p;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(img + RcImage<ROWS>::off(8 * g + q, m0 + 4 * pp)));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(img + RcImage<ROWS>::off(8 * g + 4 + q, m0 + 4 * pp)));
+    union { s16x4 s[2]; bf16x8 v; } u;
+    u.s[0] = a; u.s[1] = b;
+    return u.v;
+}
+
+template <int NI>
+__global__ __launch_bounds__(GEMM_THREADS) void k_gemm_bf3_rc(const GemmP p) {
+    constexpr int TM = 64, TN = 16 * NI;
+    constexpr int STAGE_B = 4 * 16 * (TN + 4) * 4;       // epilogue staging (bytes), overlays the operand tiles
+    constexpr int OPER_B = 2 * (RcImage<TM>::ELEMS + RcImage<TN>::ELEMS) * 2;
+    __shared__ __attribute__((aligned(256))) char s_lds[OPER_B > STAGE_B ? OPER_B : STAGE_B];
+    __bf16* Ah = (__bf16*)s_lds;
+    __bf16* Al = Ah + RcImage<TM>::ELEMS;
+    __bf16* Bh = Al + RcImage<TM>::ELEMS;
+    __bf16* Bl = Bh + RcImage<TN>::ELEMS;
+    __shared__ float s_red[4][TN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.z / p.k_split, ks = blockIdx.z - g * p.k_split;
+    const int bx = blockIdx.x, by = blockIdx.y;
+    const int m0 = by * TM, n0 = bx * TN;
+    const float* Ag = p.A + (int64_t)g * p.a_gs;
+    const float* Bg = p.B + (int64_t)g * p.b_gs;
+    const int k_begin = ks * p.k_chunk;
+    int k_end = k_begin + p.k_chunk;
+    if (k_end > p.K) k_end = p.K;
+
+    f32x4 acc[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto tile_live = [&](int k0) -> bool {
+        if (p.gate_axis != 2) return true;
+        const int s = p.tile_seg[k0 / TILE_M];
+        if (s < 0) return false;
+        return !(p.active && !p.active[s * p.active_ld + g]);
+    };
+    auto next_live = [&](int k0) -> int {
+        while (k0 < k_end && !tile_live(k0)) k0 += GEMM_BK;
+        return k0;
+    };
+    Bf3RcLoader<TM> la;
+    Bf3RcLoader<TN> lb;
+    const bool full_mn = (m0 + TM <= p.M) && (n0 + TN <= p.N);
+    auto load_tiles = [&](int kk0) {
+        if (full_mn && kk0 + GEMM_BK <= k_end) {
+            la.template load<true>(Ag, p.lda, m0, p.M, kk0, k_end);
+            lb.template load<true>(Bg, p.ldb, n0, p.N, kk0, k_end);
+        } else {
+            la.template load<false>(Ag, p.lda, m0, p.M, kk0, k_end);
+            lb.template load<false>(Bg, p.ldb, n0, p.N, kk0, k_end);
+        }
+    };
+    int k0 = next_live(k_begin);
+    if (k0 < k_end) load_tiles(k0);
+    while (k0 < k_end) {
+        la.store(Ah, Al);
+        lb.store(Bh, Bl);
+        __syncthreads();
+        const int kn = next_live(k0 + GEMM_BK);
+        if (kn < k_end) load_tiles(kn);
+        const bf16x8 ah = rc_fragment<TM>(Ah, wave * 16, lane), al = rc_fragment<TM>(Al, wave * 16, lane);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const bf16x8 bh = rc_fragment<TN>(Bh, i * 16, lane), bl = rc_fragment<TN>(Bl, i * 16, lane);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[i], 0, 0, 0);
+        }
+        __syncthreads();
+        k0 = kn;
+    }
+    gemm_epilogue<NI>(p, acc, g, ks, m0, n0, by, s_red, (float*)s_lds);
+}
+
 // number of 16-column MFMA tiles per wave: 96-wide tiles when they cover N with less padding than 128-wide ones
 static inline int gemm_ni(int N) {
     if (N > 64) {
@@ -477,3 +637,5 @@ static inline int gemm_ni(int N) {
 int launch_gemm(const GemmP& p, bool a_kc, bool b_kc, hipStream_t st);
 // split-bf16 variant: both operands k-contiguous, no split-K / k-gating
 int launch_gemm_bf3(const GemmP& p, hipStream_t st);
+// split-bf16 variant for two row-contiguous operands (weight gradients); split-K and k-tile gating as launch_gemm
+int launch_gemm_bf3_rc(const GemmP& p, hipStream_t st);

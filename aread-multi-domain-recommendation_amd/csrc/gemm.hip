@@ -54,6 +54,41 @@ int launch_gemm_bf3(const GemmP& p_in, hipStream_t st) {
     return AREAD_OK;
 }
 
+int launch_gemm_bf3_rc(const GemmP& p_in, hipStream_t st) {
+    GemmP p = p_in;
+    AR_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0 && p.G > 0, "gemm_bf3_rc: empty problem");
+    AR_CHECK_ARG(p.lda % 4 == 0 && p.ldb % 4 == 0 && p.a_gs % 4 == 0 && p.b_gs % 4 == 0, "gemm_bf3_rc: strides must be multiples of 4");
+    AR_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.B & 15) == 0, "gemm_bf3_rc: operands must be 16-byte aligned");
+    if (p.k_split < 1) p.k_split = 1;
+    if (p.k_split == 1) p.k_chunk = p.K;
+    AR_CHECK_ARG(p.k_split == 1 || p.k_chunk % TILE_M == 0, "gemm_bf3_rc: k_chunk must be a multiple of %d", TILE_M);
+    AR_CHECK_ARG(p.gate_axis == 0 || p.gate_axis == 2, "gemm_bf3_rc: only k-tile gating is supported");
+    AR_CHECK_ARG(p.gate_axis == 0 || p.tile_seg != nullptr, "gemm_bf3_rc: gating needs tile_seg");
+    const int ni = gemm_ni(p.N);
+    dim3 grid(cdiv(p.N, 16 * ni), cdiv(p.M, 64), p.G * p.k_split);
+    switch (ni) {
+        case 8: hipLaunchKernelGGL((k_gemm_bf3_rc<8>), grid, dim3(GEMM_THREADS), 0, st, p); break;
+        case 6: hipLaunchKernelGGL((k_gemm_bf3_rc<6>), grid, dim3(GEMM_THREADS), 0, st, p); break;
+        case 4: hipLaunchKernelGGL((k_gemm_bf3_rc<4>), grid, dim3(GEMM_THREADS), 0, st, p); break;
+        case 2: hipLaunchKernelGGL((k_gemm_bf3_rc<2>), grid, dim3(GEMM_THREADS), 0, st, p); break;
+        default: hipLaunchKernelGGL((k_gemm_bf3_rc<1>), grid, dim3(GEMM_THREADS), 0, st, p); break;
+    }
+    AR_LAUNCH_CHECK();
+    return AREAD_OK;
+}
+
+extern "C" int aread_gemm_bf16x3_rc(const float* A, int64_t lda, int64_t a_gs, const float* B, int64_t ldb, int64_t b_gs, float* C,
+                                    int64_t ldc, int64_t c_gs, int M, int N, int K, int G, int accumulate, void* stream) {
+    GemmP p = {};
+    p.A = A; p.lda = lda; p.a_gs = a_gs;
+    p.B = B; p.ldb = ldb; p.b_gs = b_gs;
+    p.C = C; p.ldc = ldc; p.c_gs = c_gs;
+    p.M = M; p.N = N; p.K = K; p.G = G;
+    p.accumulate = accumulate;
+    AR_CHECK_ARG(A && B && C, "aread_gemm_bf16x3_rc: null pointer");
+    return launch_gemm_bf3_rc(p, (hipStream_t)stream);
+}
+
 extern "C" int aread_gemm(const float* A, int64_t lda, int64_t a_gs, int a_kc, const float* B, int64_t ldb,
                           int64_t b_gs, int b_kc, float* C, int64_t ldc, int64_t c_gs, const float* bias,
                           int64_t bias_gs, int M, int N, int K, int G, int accumulate, void* stream) {

@@ -219,7 +219,7 @@ def main():
 
     if args.kernels_only:
         res = {"gemm_roofline": measure_gemm_kernel(model, bufs, L, B, args.precision),
-               "wgrad_roofline": measure_wgrad_kernel(model, bufs, L, B), "l2_table_roofline": measure_l2_kernel(model, bufs, L),
+               "wgrad_roofline": measure_wgrad_kernel(model, bufs, L, B, args.precision), "l2_table_roofline": measure_l2_kernel(model, bufs, L),
                "gather_roofline": measure_gather_kernel(model, xs, bufs, L), "note": "--kernels-only profiling run"}
         if rank == 0:
             os.write(json_fd, (json.dumps(res) + "\n").encode())
@@ -259,7 +259,7 @@ def main():
         return
     # ---- roofline of the dominant kernel: the dense-L2 table sweep (read table, write dense gradient) ----
     gemm = measure_gemm_kernel(model, bufs, L, B, args.precision)
-    wgrad = measure_wgrad_kernel(model, bufs, L, B)
+    wgrad = measure_wgrad_kernel(model, bufs, L, B, args.precision)
     l2pass = measure_l2_kernel(model, bufs, L)
     gather = measure_gather_kernel(model, xs, bufs, L)
     big_x = torch.cat([bt[0] for bt in batches] * 2, dim=0)                  # 65 536 samples: latency amortised
@@ -363,20 +363,32 @@ def measure_gemm_kernel(model, bufs, L, B, precision):
             "mfma": "v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate)"}
 
 
-def measure_wgrad_kernel(model, bufs, L, B):
-    """Expert layer 1 weight gradient dW1[1024,288] = dZ[rows,1024]^T . E[rows,288] (k_gemm<6,false,false>: fp32 MFMA, both
-    operands row-contiguous, K = the batch rows cut into 16 split-K slices exactly as the model's backward launches it --
-    expressed here through the public grouped entry point: one group per slice).  The longest single launch of the step."""
+def measure_wgrad_kernel(model, bufs, L, B, precision):
+    """Expert layer 1 weight gradient dW1[1024,288] = dZ[rows,1024]^T . E[rows,288]: both operands row-contiguous, K = the
+    batch rows cut into 16 split-K slices exactly as the model's backward launches it -- expressed here through the public
+    grouped entry points: one group per slice.  fp32 mode: k_gemm<6,false,false> (fp32 MFMA); split-bf16 mode:
+    k_gemm_bf3_rc<6> (k-major tiles, transposing LDS reads, 3 bf16 MFMA products)."""
     rows, D = bufs["e"].shape
     h1 = model.expert_dims[0] * int(model._cfg.n_expert)
     k_split = 16
     k_chunk = rows // k_split
     dz = torch.randn((rows, h1), device=bufs["e"].device)
     slab = torch.empty((k_split, h1, D), device=dz.device)
+    alg = 2.0 * D * h1 * B
+    if precision == "bf16x3":
+        fn = lambda: L.check(L.lib().aread_gemm_bf16x3_rc(L.ptr(dz), h1, k_chunk * h1, L.ptr(bufs["e"]), D, k_chunk * D, L.ptr(slab),
+                                                          D, h1 * D, h1, D, k_chunk, k_split, 0, L.stream()))
+        t = _time_kernel(fn)
+        ach = alg / t / 1e12
+        return {"kernel": "k_gemm_bf3_rc<6> (expert layer 1 weight gradient, split-bf16, split-K 16)", "bound": "mfma",
+                "achieved": round(ach, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4),
+                "issued_frac": round(3 * ach * rows / B / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": _pmc_traffic("k_gemm_bf3_rc<6>"),
+                "algorithmic_flops_per_launch": alg, "issued_flops_per_launch": 3 * 2.0 * D * h1 * k_chunk * k_split,
+                "avg_launch_us": round(t * 1e6, 2),
+                "mfma": "v_mfma_f32_16x16x32_bf16 x3, operands read with ds_read_b64_tr_b16, f32 accumulate"}
     fn = lambda: L.check(L.lib().aread_gemm(L.ptr(dz), h1, k_chunk * h1, 0, L.ptr(bufs["e"]), D, k_chunk * D, 0, L.ptr(slab), D,
                                             h1 * D, None, 0, h1, D, k_chunk, k_split, 0, L.stream()))
     t = _time_kernel(fn)
-    alg = 2.0 * D * h1 * B
     ach = alg / t / 1e12
     return {"kernel": "k_gemm<6,false,false> (expert layer 1 weight gradient, split-K 16)", "bound": "mfma",
             "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4),

@@ -155,6 +155,11 @@ int aread_gemm(const float* A, int64_t lda, int64_t a_gs, int a_kc,
 int aread_gemm_bf16x3(const float* A, int64_t lda, int64_t a_gs, const float* B, int64_t ldb, int64_t b_gs,
                       float* C, int64_t ldc, int64_t c_gs, const float* bias, int64_t bias_gs,
                       int M, int N, int K, int G, int accumulate, void* stream);
+/* The same split-bf16 product for two ROW-contiguous operands (element (r,k) at base + g*gs + k*ld + r): the shape of
+ * every weight gradient dW = dH^T X of the path (autograd of torch.nn.Linear, model/layer.py:209-229), K = batch rows.
+ * The k-major tiles are staged untransposed and read with the CDNA4 transposing LDS read (ds_read_b64_tr_b16). */
+int aread_gemm_bf16x3_rc(const float* A, int64_t lda, int64_t a_gs, const float* B, int64_t ldb, int64_t b_gs,
+                         float* C, int64_t ldc, int64_t c_gs, int M, int N, int K, int G, int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense part of the model: linear term, cross network, MMoE bottom, masked HEI tower pyramid, heads,

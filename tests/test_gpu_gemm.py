@@ -79,3 +79,37 @@ def test_gemm_bf16x3(M, N, K, G):
     assert err < 2e-5, err
     assert np.sqrt(((C[:, :, :N] - ref) ** 2).mean()) / np.sqrt((ref ** 2).mean()) < 1e-5
     assert (C[:, :, N:] == 7.0).all()
+
+
+@pytest.mark.parametrize("M,N,K,G", [(64, 16, 32, 1), (1024, 288, 9728, 1), (128, 256, 2432, 4), (100, 90, 70, 1), (64, 128, 640, 3),
+                                       (12, 64, 1000, 1), (32, 32, 96, 6), (16, 16, 64, 12), (288, 4, 9728, 1)])
+def test_gemm_bf16x3_row_contiguous(M, N, K, G):
+    """weight-gradient shape: both operands row-contiguous (k-major), transposing LDS reads; ~1e-6 relative error
+    against float64; exact integer products (also checks the k order / fragment layout bit for bit)."""
+    from aread_amd import _lib as L
+    rng = np.random.default_rng(M + N + K + G)
+    pad = lambda n: (n + 3) // 4 * 4
+    a = rng.standard_normal((G, K, M)).astype(np.float32)             # A[g](m,k) stored at [g][k][m]
+    b = rng.standard_normal((G, K, N)).astype(np.float32)
+    A = np.zeros((G, K, pad(M)), np.float32); A[:, :, :M] = a
+    Bm = np.zeros((G, K, pad(N)), np.float32); Bm[:, :, :N] = b
+    ldc = pad(N) + 4
+    C = torch.full((G, M, ldc), 7.0, device="cuda")
+    Ad, Bd = torch.from_numpy(A).cuda(), torch.from_numpy(Bm).cuda()
+    L.check(L.lib().aread_gemm_bf16x3_rc(L.ptr(Ad), pad(M), K * pad(M), L.ptr(Bd), pad(N), K * pad(N), L.ptr(C), ldc, M * ldc,
+                                         M, N, K, G, 0, L.stream()))
+    torch.cuda.synchronize()
+    Cn = C.cpu().numpy()
+    ref = np.einsum("gkm,gkn->gmn", a.astype(np.float64), b.astype(np.float64))
+    assert np.abs(Cn[:, :, :N] - ref).max() / np.abs(ref).max() < 2e-5
+    assert np.sqrt(((Cn[:, :, :N] - ref) ** 2).mean()) / np.sqrt((ref ** 2).mean()) < 1e-5
+    assert (Cn[:, :, N:] == 7.0).all()
+    # small integers are exact in bf16: the product must be bit-exact
+    ai = rng.integers(-3, 4, (G, K, pad(M))).astype(np.float32); ai[:, :, M:] = 0
+    bi = rng.integers(-3, 4, (G, K, pad(N))).astype(np.float32); bi[:, :, N:] = 0
+    C2 = torch.zeros((G, M, ldc), device="cuda")
+    aid, bid = torch.from_numpy(ai).cuda(), torch.from_numpy(bi).cuda()
+    L.check(L.lib().aread_gemm_bf16x3_rc(L.ptr(aid), pad(M), K * pad(M), L.ptr(bid), pad(N), K * pad(N), L.ptr(C2), ldc, M * ldc,
+                                         M, N, K, G, 0, L.stream()))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(C2.cpu().numpy()[:, :, :N], np.einsum("gkm,gkn->gmn", ai[:, :, :M], bi[:, :, :N]))

@@ -27,6 +27,7 @@ mom, var = torch.zeros_like(table), torch.zeros_like(table)
 dz = torch.randn(M * N, device="cuda"); slab = torch.empty(16 * N * K, device="cuda"); kc = M // 16
 for _ in range(5):
     L.check(L.lib().aread_gemm(L.ptr(dz), N, kc * N, 0, L.ptr(A), K, kc * K, 0, L.ptr(slab), K, N * K, None, 0, N, K, kc, 16, 0, L.stream()))
+    L.check(L.lib().aread_gemm_bf16x3_rc(L.ptr(dz), N, kc * N, L.ptr(A), K, kc * K, L.ptr(slab), K, N * K, N, K, kc, 16, 0, L.stream()))
     L.check(L.lib().aread_gemm_bf16x3(L.ptr(A), K, M * K, L.ptr(B), K, N * K, L.ptr(C), N, M * N, None, 0, M, N, K, 1, 0, L.stream()))
     L.check(L.lib().aread_adam_table_l2(L.ptr(table), L.ptr(mom), L.ptr(var), R, 32, None, None, None, None, 1e-5, ct.byref(cfg), 0,
                                         L.ptr(part), L.stream()))
