@@ -582,9 +582,11 @@ class AREAD(HempMixin, nn.Module):
         main, side = torch.cuda.current_stream(), self._side_stream(x.device)
         part = self._l2_partials(x.device)
         self.embedding._ws_for(x)                      # allocate on the main stream's pool before forking
-        # Host issue order matters (eager launches): the table L2 pass needs nothing from this batch and goes first on
-        # the side stream; then the main stream gets its whole forward; only then the index sort (which needs the row
-        # plan, not the forward) is queued on the side stream, so the main stream never waits for the host.
+        # Host issue order matters (eager launches): row plan, then the table L2 pass on the side stream, then the main
+        # stream gets its whole forward; only then the index sort (which needs the row plan, not the forward) is queued
+        # on the side stream, so the main stream never waits for the host.
+        if plan is None:                               # first on the main stream: everything else waits for it, and it is
+            plan = RowPlan(x, self.domain_idx if n_seg > 1 else -1, n_seg)     # latency-bound (slow next to the HBM-saturating L2 pass)
         side.wait_stream(main)
         with torch.cuda.stream(side):
             if not table_pass:
@@ -597,8 +599,6 @@ class AREAD(HempMixin, nn.Module):
             else:
                 gtable.zero_()
                 bufs["reg"].zero_()
-        if plan is None:
-            plan = RowPlan(x, self.domain_idx if n_seg > 1 else -1, n_seg)
         if presort:
             plan_ready = torch.cuda.Event()
             plan_ready.record(main)
