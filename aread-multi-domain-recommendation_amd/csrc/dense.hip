@@ -128,6 +128,28 @@ static int simple_gemm(Ctx& x, const float* A, int64_t lda, bool a_kc, const flo
     return launch_gemm(g, a_kc, b_kc, x.st);
 }
 
+// transposed weight copies [g][in][out] for the split-bf16 dgrad of the backward (it wants k-contiguous operands);
+// launched on x.st for every Linear of the model's stacks
+static int transpose_weights(Ctx& x) {
+    const aread_model* m = x.m;
+    TransAllP ta = {};
+    int64_t mx = 0;
+    auto add = [&](const LayerL& L, const LayerWs& lw) {
+        const bool sh = (L.in_gs == 0 && L.G > 1) || L.G == 1;
+        TransOne& d = ta.d[ta.n++];
+        d.W = x.params + L.w; d.WT = x.ws + lw.wT; d.G = sh ? 1 : L.G; d.out = sh ? L.ncols : L.out_dim; d.in = L.in_dim;
+        if ((int64_t)L.ncols * L.in_dim > mx) mx = (int64_t)L.ncols * L.in_dim;
+    };
+    for (int j = 0; j < m->experts.n_layers; ++j) add(m->experts.L[j], x.w.ex[j]);
+    if (!m->is_mlp)
+        for (int l = 0; l < m->cfg.n_level; ++l)
+            for (int j = 0; j < m->towers[l].n_layers; ++j) add(m->towers[l].L[j], x.w.tw[l][j]);
+    int bx = cdiv(mx, 256);
+    if (bx > 256) bx = 256;
+    LAUNCH(k_transpose_weights, dim3(bx, ta.n), dim3(256), ta);
+    return AREAD_OK;
+}
+
 template <int MAXV>
 static void launch_rowwise_fwd(Ctx& x, const RowwiseP& p) {
     hipLaunchKernelGGL((k_rowwise_fwd<MAXV>), dim3(x.n_tiles * SUB), dim3(256), 0, x.st, p);
@@ -159,22 +181,7 @@ extern "C" int aread_forward(const aread_model* m, const aread_call* c, const fl
         x.st = x.side;
         LAUNCH(k_mask_prep, dim3(1), dim3(256), mp);
         if (c->probs) AR_HIP(hipMemsetAsync(c->probs, 0, (size_t)m->n_heads * c->B * sizeof(float), x.st));
-        if (c->train && cfg.precision == 1) {          // transposed weights for the split-bf16 dgrad of the backward
-            TransAllP ta = {};
-            int64_t mx = 0;
-            auto add = [&](const LayerL& L, const LayerWs& lw) {
-                const bool sh = (L.in_gs == 0 && L.G > 1) || L.G == 1;
-                TransOne& d = ta.d[ta.n++];
-                d.W = P + L.w; d.WT = ws + lw.wT; d.G = sh ? 1 : L.G; d.out = sh ? L.ncols : L.out_dim; d.in = L.in_dim;
-                if ((int64_t)L.ncols * L.in_dim > mx) mx = (int64_t)L.ncols * L.in_dim;
-            };
-            for (int j = 0; j < m->experts.n_layers; ++j) add(m->experts.L[j], x.w.ex[j]);
-            for (int l = 0; l < cfg.n_level; ++l)
-                for (int j = 0; j < m->towers[l].n_layers; ++j) add(m->towers[l].L[j], x.w.tw[l][j]);
-            int bx = cdiv(mx, 256);
-            if (bx > 256) bx = 256;
-            LAUNCH(k_transpose_weights, dim3(bx, ta.n), dim3(256), ta);
-        }
+        if (c->train && cfg.precision == 1) TRY(transpose_weights(x));
         RowwiseP rw = {};
         rw.e = e_in; rw.cn = ws + x.w.cn; rw.lin = ws + x.w.lin; rw.xw = ws + x.w.xw; rw.q = ws + x.w.q; rw.grp = ws + x.w.grp;
         rw.lin_w = P + m->lin_w; rw.lin_b = P + m->lin_b; rw.cn_w = P + m->cn_w; rw.cn_b = P + m->cn_b;
@@ -574,6 +581,7 @@ extern "C" int aread_mlp_forward(const aread_model* m, const aread_mlp_call* c, 
     float* ws = x.ws;
     const int in = m->mlp_in, nl = m->experts.n_layers, last = m->h_last;
     LAUNCH(k_pad_rows, dim3(cdiv(x.rows * in, 256)), dim3(256), xin, (int64_t)in, ws + x.w.In[0], (int64_t)in, in, c->B, x.rows);
+    if (c->train && m->cfg.precision == 1) TRY(transpose_weights(x));      // for the split-bf16 dgrad of aread_mlp_backward
     TRY(stack_fwd(x, m->experts, x.w.ex, ws + x.w.In[0], -1));
     const float* act = ws + x.w.ex[nl - 1].Act;
     if (m->mlp_out_layer) {

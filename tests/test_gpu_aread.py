@@ -434,3 +434,26 @@ def test_aliccp_layout_step_vs_oracle(precision, ltol, gfac):
     # entries by percents), so the bound is norm-wise over all gradients together
     assert (num / den) ** 0.5 <= (1e-3 if precision == "f32" else 3e-2), (num / den) ** 0.5
     assert checked > 200
+
+
+def test_multilayer_perceptron_split_bf16_backward():
+    """MultiLayerPerceptron(precision='bf16x3'): forward, input gradient (the dgrad uses transposed weight copies made in
+    the forward) and weight gradients against the fp32-mode module."""
+    import aread_amd
+    torch.manual_seed(5)
+    dims, in_dim, B = (64, 32, 16), 96, 500
+    a = aread_amd.MultiLayerPerceptron(in_dim, dims, 0.0, output_layer=True).cuda()
+    b = aread_amd.MultiLayerPerceptron(in_dim, dims, 0.0, output_layer=True, precision="bf16x3").cuda()
+    b.load_state_dict(a.state_dict(), strict=True)
+    a.train(); b.train()
+    x = torch.randn(B, in_dim, device="cuda")
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya, yb = a(xa), b(xb)
+    np.testing.assert_allclose(yb.detach().cpu().numpy(), ya.detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
+    w = torch.randn_like(ya)
+    (ya * w).sum().backward()
+    (yb * w).sum().backward()
+    ga, gb = xa.grad.cpu().numpy(), xb.grad.cpu().numpy()
+    assert np.abs(gb - ga).max() <= 2e-3 * np.abs(ga).max()
+    da, db = a.dense.grad.cpu().numpy(), b.dense.grad.cpu().numpy()
+    assert np.linalg.norm(db - da) <= 2e-3 * np.linalg.norm(da)
