@@ -272,7 +272,7 @@ def main():
         else f"CTR samples/s fwd+bwd, AREAD 30-domain (AliCCP layout) batch={B}", "value": round(value, 1), "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.precision == "f32" else "bf16x3 (split-bf16 fwd/dgrad GEMMs, fp32 accumulate) + f32",
+        "dtype": "f32" if args.precision == "f32" else "bf16x3 (split-bf16 fwd/dgrad/wgrad GEMMs: 3 bf16 MFMA products, fp32 accumulate) + f32 elsewhere",
         "data": "synthetic",
         "config": {"workload": ("AREAD HEI+HEMP-mask fwd+bagging BCE+L2+bwd, Amazon-like 25-domain, dims "
                                 "[1368287,7,25,45,11,22356,10], E=32, 17 id columns, experts 4x(256,128,64), towers 3/6/12")
