@@ -27,7 +27,7 @@ F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 run
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -52,7 +52,10 @@ def parse():
     ap.add_argument("--table", default="auto", choices=["auto", "replicated", "sharded"],
                     help="multi-GPU embedding table: replicated (all_gather of ids/dE) or row-sharded (all_to_all lookup, "
                          "reduce_scatter of the dense gradient); auto times both briefly and keeps the faster")
-    return ap.parse_args()
+    ap.add_argument("--stub-step", action="store_true", help="testing the launcher without a GPU: ranks rendezvous over gloo "
+                    "on the CPU and time a stand-in step (a sleep + one all_reduce); the JSON line says so")
+    ap.add_argument("--rank-timeout", type=float, default=1500.0, help="launcher: seconds before the ranks are given up on")
+    return ap.parse_args(argv)
 
 
 def build(spec, device, seed=123, precision="f32"):
@@ -67,16 +70,131 @@ def log(msg):
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with no rank environment: this process becomes the launcher.  It starts N fresh
+    child processes (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) BEFORE anything here touches the GPU,
+    forwards rank 0's JSON line and returns non-zero if any rank fails.  (The driver's own
+    `python -m torch.distributed.run ... bench.py --gpus N` sets WORLD_SIZE and never comes through here.)"""
+    import subprocess
+    n = args.gpus
+    if not args.stub_step:
+        have = torch.cuda.device_count()          # does not initialise the HIP runtime
+        if have < n:
+            print(f"[bench] --gpus {n} but only {have} device(s) are visible", file=sys.stderr)
+            return 2
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    deadline = time.time() + args.rank_timeout
+    rc, out0 = 0, b""
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if r == 0:
+                out0 = procs[0].stdout.read()
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"[bench] rank {r} exited with {code}", file=sys.stderr)
+        if alive and (rc != 0 or time.time() > deadline):
+            if rc == 0:
+                rc = 124
+                print(f"[bench] ranks {sorted(alive)} still running after {args.rank_timeout:.0f} s", file=sys.stderr)
+            for r in alive:                       # exactly the processes started above
+                procs[r].terminate()
+            t_kill = time.time() + 10
+            for r in sorted(alive):
+                try:
+                    procs[r].wait(timeout=max(0.1, t_kill - time.time()))
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+                    procs[r].wait()
+            break
+        if alive:
+            time.sleep(0.05)
+    lines = [ln for ln in out0.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if rc == 0 and not lines:
+        print("[bench] rank 0 printed no JSON line", file=sys.stderr)
+        rc = 1
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    return rc
+
+
+def stub_main(args, json_fd):
+    """The launcher's contract without a GPU (tests/test_bench_launcher.py): gloo rendezvous, barrier-bracketed timed
+    region, MAX over ranks, one JSON line from rank 0."""
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.zeros(1)
+
+    def step():
+        time.sleep(0.002)
+        if world > 1:
+            dist.all_reduce(t)
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        got = dist.get_world_size()
+        dist.destroy_process_group()
+    else:
+        got = 1
+    if rank == 0:
+        os.write(json_fd, (json.dumps({"metric": "stub step (launcher test)", "value": round(world * args.batch * args.steps / float(dt), 1),
+                                       "unit": "samples/s", "n_gpus": got, "steps": args.steps, "warmup": args.warmup,
+                                       "ms_per_step": round(float(dt) / args.steps * 1e3, 4), "data": "none", "stub": True}) + "\n").encode())
+
+
 def main():
-    args = parse()
+    argv = sys.argv[1:]
+    args = parse(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args, argv))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU (python bench.py --gpus N does)",
+              file=sys.stderr)
+        sys.exit(2)
     # stdout carries exactly one JSON line: everything else (RCCL prints a version banner on fd 1) goes to stderr
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    if args.stub_step:
+        return stub_main(args, json_fd)
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.device_count() <= local_rank:
+        print(f"[bench] rank {rank}: no device {local_rank} ({torch.cuda.device_count()} visible)", file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dp = world > 1 or args.force_dp
@@ -84,6 +202,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dist.get_world_size() != args.gpus and not args.force_dp:
+            raise RuntimeError(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
 
     from oracle import aread_oracle as O          # spec + deterministic initialiser (+ cpu_baseline leg below)
     from tools import synth
@@ -199,20 +319,14 @@ def main():
     if use_dp and args.table == "auto":
         times = {}
         for name in variants:
+            # no try/except here: an exception on ONE rank inside a collective would leave the other ranks waiting in it;
+            # a failing variant is fatal, the launcher (or torchrun) then ends every rank
             dp_state["variant"] = name
-            try:                                     # a variant that fails the same way on every rank is skipped, not fatal
-                quick(3)
-                dist.barrier()
-                t_var, failed = quick(), 0.0
-            except Exception as exc:                 # noqa: BLE001
-                log(f"table variant {name} failed: {type(exc).__name__}: {exc}")
-                t_var, failed = 1e9, 1.0
-            tt = torch.tensor([t_var, failed], device=dev, dtype=torch.float64)
+            quick(3)
+            dist.barrier()
+            tt = torch.tensor([quick()], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            if float(tt[1]) == 0.0:
-                times[name] = float(tt[0])
-        if not times:
-            raise RuntimeError("no multi-GPU table variant ran")
+            times[name] = float(tt[0])
         dp_state["variant"] = min(times, key=times.get)
         dp_state["times_ms"] = {k: round(v * 1e3, 4) for k, v in times.items()}
         log(f"table variant: {dp_state['times_ms']} -> {dp_state['variant']}")
