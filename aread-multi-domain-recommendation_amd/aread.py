@@ -243,6 +243,8 @@ class AREAD(HempMixin, nn.Module):
         self._drop_calls = 0
         self._pending_dense_l2 = False
         self.drop_seed_base = 0
+        import os
+        self.l2_pass_workgroups = int(os.environ.get("AREAD_L2_WG", "0"))   # width of the table L2 sweep inside the fused step
         self.drop_seed = None          # set to an int to pin the dropout stream (tests)
         self._register_state_dict_hook(AREAD._sd_hook)
         self._register_load_state_dict_pre_hook(self._load_hook)
@@ -592,8 +594,10 @@ class AREAD(HempMixin, nn.Module):
             if not table_pass:
                 bufs["reg"].zero_()
             elif with_reg:
-                L.check(lib.aread_l2_table(L.ptr(table), table.numel(), self.l2_reg_embedding, 1.0, L.ptr(gtable),
-                                           L.ptr(part), L.stream()))
+                # a background sweep on a few workgroups: the 356 MB stream would otherwise take the HBM bandwidth away
+                # from the latency-bound head of the critical path (row plan, gather); it has the whole forward to finish
+                L.check(lib.aread_l2_table_throttled(L.ptr(table), table.numel(), self.l2_reg_embedding, 1.0, L.ptr(gtable),
+                                                     L.ptr(part), self.l2_pass_workgroups, L.stream()))
                 L.check(lib.aread_l2_finish(L.ptr(part), part.numel(), self.l2_reg_embedding, L.ptr(bufs["reg"]), 0,
                                             L.stream()))
             else:

@@ -2,8 +2,9 @@
 // No allocation, no synchronisation, no host<->device copy: the whole sequence can be captured
 // into a hipGraph by the caller.
 #include <cstring>
+#include <cstdlib>
 #include "dense_bwd_kernels.h"
-#include "gemm.h"
+#include "gemm_wide.h"
 
 
 struct Ctx {
@@ -85,6 +86,46 @@ static const uint8_t* level_active(const Ctx& x, int level) {
     return level >= 0 ? x.mp.active + (size_t)level * MAX_SEG * MAX_TOWER : nullptr;
 }
 
+// ---- pre-tiled split-bf16 weight images for the wide GEMM (gemm_wide.h) ------------------------------------------
+static bool layer_one_group(const LayerL& L) { return (L.in_gs == 0 && L.G > 1) || L.G == 1; }
+static WImgDesc wimg_desc(const Ctx& x, const LayerL& L, const LayerWs& lw, bool dgrad) {
+    const bool one = layer_one_group(L);
+    const int N = dgrad ? L.in_dim : (one ? L.ncols : L.out_dim), K = dgrad ? (one ? L.ncols : L.out_dim) : L.in_dim;
+    WImgDesc w;
+    w.img = (const __bf16*)(x.ws + (dgrad ? lw.wimg_d : lw.wimg_f));
+    w.NF = wide_nf(N); w.NT = (N + 32 * w.NF - 1) / (32 * w.NF); w.KS = (K + 31) / 32;
+    return w;
+}
+// which == 0: forward images, 1: dgrad images.  One launch for every Linear of the model's stacks, on x.st.
+static int prepare_wimg(Ctx& x, int which) {
+    const aread_model* m = x.m;
+    WPrepAllP a = {};
+    auto add = [&](const LayerL& L, const LayerWs& lw) {
+        const bool one = layer_one_group(L);
+        const int out = one ? L.ncols : L.out_dim;
+        WPrepOne& d = a.d[a.n++];
+        d.W = x.params + L.w; d.G = one ? 1 : L.G; d.gs = (int64_t)L.out_dim * L.in_dim;
+        if (which == 0) { d.N = out; d.K = L.in_dim; d.sn = L.in_dim; d.sk = 1; d.img = (__bf16*)(x.ws + lw.wimg_f); }
+        else { d.N = L.in_dim; d.K = out; d.sn = 1; d.sk = L.in_dim; d.img = (__bf16*)(x.ws + lw.wimg_d); }
+        d.NF = wide_nf(d.N); d.NT = (d.N + 32 * d.NF - 1) / (32 * d.NF); d.KS = (d.K + 31) / 32;
+    };
+    for (int j = 0; j < m->experts.n_layers; ++j) add(m->experts.L[j], x.w.ex[j]);
+    if (!m->is_mlp)
+        for (int l = 0; l < m->cfg.n_level; ++l)
+            for (int j = 0; j < m->towers[l].n_layers; ++j) add(m->towers[l].L[j], x.w.tw[l][j]);
+    AR_CHECK_ARG(a.n <= WPREP_MAX, "too many layers for one weight-image launch");
+    return launch_prep_wimg(a, x.st);
+}
+static int g_wide_mode = -1;      // AREAD_WIDE: 0 = 64-row kernels everywhere (default: measured equal or faster in the step), 1 = wide kernel for the experts, 2 = for every layer
+static bool use_wide(const Ctx& x, const LayerL& L) {
+    if (g_wide_mode < 0) {
+        const char* e = getenv("AREAD_WIDE");
+        g_wide_mode = e ? atoi(e) : 0;
+    }
+    if (x.m->cfg.precision != 1 || g_wide_mode == 0) return false;
+    return g_wide_mode >= 2 || L.stack == 0;
+}
+
 // ---- one MLP layer forward: H = in W^T + b (statistics in the epilogue) ; finalize ; BN+ReLU+dropout ----
 static int layer_fwd(Ctx& x, const LayerL& L, const LayerWs& lw, const float* in, int level) {
     const bool shared = L.in_gs == 0 && L.G > 1;
@@ -98,7 +139,8 @@ static int layer_fwd(Ctx& x, const LayerL& L, const LayerWs& lw, const float* in
     g.gate_axis = 1; g.tile_seg = x.r.tile_seg; g.tile_valid = x.r.tile_valid;
     g.active = (level >= 0 && g.G > 1) ? level_active(x, level) : nullptr; g.active_ld = MAX_TOWER;
     if (x.c->train) { g.stat_part = x.ws + lw.part; g.stat_ld = L.ncols; }
-    if (x.m->cfg.precision == 1) TRY(launch_gemm_bf3(g, x.st));
+    if (use_wide(x, L)) TRY(launch_gemm_bf3w(g, wimg_desc(x, L, lw, false), x.st));
+    else if (x.m->cfg.precision == 1) TRY(launch_gemm_bf3(g, x.st));
     else TRY(launch_gemm(g, true, true, x.st));
     BnActP a = {};
     a.H = x.ws + lw.H; a.Act = x.ws + lw.Act; a.part = x.ws + lw.part;
@@ -173,6 +215,7 @@ extern "C" int aread_forward(const aread_model* m, const aread_call* c, const fl
     mp.group_emb = P + m->group_emb;
     mp.active = (uint8_t*)(ws + x.w.active); mp.kact = (int32_t*)(ws + x.w.kact); mp.n0act = mp.kact + MAX_SEG;
     mp.seg_dom = (int32_t*)(ws + x.w.seg_dom); mp.grp = ws + x.w.grp;
+    if (cfg.precision == 1) TRY(prepare_wimg(x, 0));        // forward weight images: the first expert GEMM needs them
     // 1.-3. (side stream, joined before the MMoE mix: the expert layers need none of it) mask tables, row-wise trunk,
     // gate logits, cross-network part of the heads
     TRY(fork_side(x));
@@ -181,7 +224,7 @@ extern "C" int aread_forward(const aread_model* m, const aread_call* c, const fl
         x.st = x.side;
         LAUNCH(k_mask_prep, dim3(1), dim3(256), mp);
         if (c->probs) AR_HIP(hipMemsetAsync(c->probs, 0, (size_t)m->n_heads * c->B * sizeof(float), x.st));
-        if (c->train && cfg.precision == 1) TRY(transpose_weights(x));
+        if (c->train && cfg.precision == 1) { TRY(transpose_weights(x)); TRY(prepare_wimg(x, 1)); }
         RowwiseP rw = {};
         rw.e = e_in; rw.cn = ws + x.w.cn; rw.lin = ws + x.w.lin; rw.xw = ws + x.w.xw; rw.q = ws + x.w.q; rw.grp = ws + x.w.grp;
         rw.lin_w = P + m->lin_w; rw.lin_b = P + m->lin_b; rw.cn_w = P + m->cn_w; rw.cn_b = P + m->cn_b;
@@ -343,7 +386,8 @@ static int layer_bwd(Ctx& x, const LayerL& L, const LayerWs& lw, const float* in
         g.M = (int)x.rows; g.N = L.in_dim; g.K = L.out_dim; g.G = L.G; g.accumulate = accumulate_d_in;
         if (shared || L.G == 1) { g.K = L.ncols; g.G = 1; g.a_gs = 0; g.b_gs = 0; g.c_gs = 0; }
         g.gate_axis = 1; g.tile_seg = x.r.tile_seg; g.tile_valid = x.r.tile_valid;
-        if (x.m->cfg.precision == 1) {              // k-contiguous B from the transposed weight copy [g][in][out]
+        if (use_wide(x, L)) TRY(launch_gemm_bf3w(g, wimg_desc(x, L, lw, true), x.st));
+        else if (x.m->cfg.precision == 1) {         // k-contiguous B from the transposed weight copy [g][in][out]
             g.B = x.ws + lw.wT;
             g.ldb = (shared || L.G == 1) ? L.ncols : L.out_dim;
             g.b_gs = (shared || L.G == 1) ? 0 : (int64_t)L.in_dim * L.out_dim;
@@ -357,18 +401,18 @@ static int layer_bwd(Ctx& x, const LayerL& L, const LayerWs& lw, const float* in
     return AREAD_OK;
 }
 
-template <int NC, int MAXV>
+template <int NC, int NV>
 static void launch_rowwise_bwd2(Ctx& x, const RowwiseBwdP& p) {
-    hipLaunchKernelGGL((k_rowwise_bwd<NC, MAXV>), dim3(x.n_tiles * SUB), dim3(256), 0, x.st, p);
+    hipLaunchKernelGGL((k_rowwise_bwd<NC, NV>), dim3(x.n_tiles * RWB_SUB), dim3(256), 0, x.st, p);
 }
-template <int MAXV>
+template <int NV>
 static void launch_rowwise_bwd(Ctx& x, const RowwiseBwdP& p) {
     switch (p.n_cross) {
-        case 0: launch_rowwise_bwd2<0, MAXV>(x, p); break;
-        case 1: launch_rowwise_bwd2<1, MAXV>(x, p); break;
-        case 2: launch_rowwise_bwd2<2, MAXV>(x, p); break;
-        case 3: launch_rowwise_bwd2<3, MAXV>(x, p); break;
-        default: launch_rowwise_bwd2<4, MAXV>(x, p); break;
+        case 0: launch_rowwise_bwd2<0, NV>(x, p); break;
+        case 1: launch_rowwise_bwd2<1, NV>(x, p); break;
+        case 2: launch_rowwise_bwd2<2, NV>(x, p); break;
+        case 3: launch_rowwise_bwd2<3, NV>(x, p); break;
+        default: launch_rowwise_bwd2<4, NV>(x, p); break;
     }
 }
 
@@ -491,28 +535,28 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     RowwiseBwdP rb = {};
     rb.e = e_in; rb.xw = ws + x.w.xw; rb.dcn = ws + x.w.dcn; rb.dlin = ws + x.w.dlin; rb.dq = ws + x.w.dq; rb.deg = ws + x.w.deg;
     rb.lin_w = P + m->lin_w; rb.cn_w = P + m->cn_w; rb.cn_b = P + m->cn_b;
-    rb.de = de_out; rb.part = ws + x.w.rw_part; rb.part_ld = (int64_t)(2 * cfg.n_cross + 1) * D + 4; rb.dgrp_part = ws + x.w.dgrp_part;
+    rb.de = de_out; rb.part = ws + x.w.rw_part; rb.part_ld = (int64_t)(cfg.n_cross + 2) * D + 8; rb.dgrp_part = ws + x.w.dgrp_part;
     rb.D = D; rb.E = E; rb.n_cross = cfg.n_cross; rb.dom_field = cfg.domain_field; rb.rows = x.rows; rb.r = x.r;
-    if (D <= 256) launch_rowwise_bwd<1>(x, rb); else if (D <= 512) launch_rowwise_bwd<2>(x, rb); else launch_rowwise_bwd<4>(x, rb);
+    AR_CHECK_ARG(D <= 1024 && cfg.n_cross <= MAX_CROSS, "aread_backward: D=%d > 1024 or too many cross layers", D);
+    if (D <= 384) launch_rowwise_bwd<3>(x, rb); else if (D <= 768) launch_rowwise_bwd<6>(x, rb); else launch_rowwise_bwd<8>(x, rb);
     AR_LAUNCH_CHECK();
     // 8. everything that only finishes parameter gradients runs on the side stream
     TRY(fork_side(x));
     x.st = x.side;
     {
-        ReduceMultiP rm = {};
-        rm.part = ws + x.w.rw_part; rm.ld = rb.part_ld; rm.sub = SUB; rm.r = x.r;
-        int c = 0;
-        auto range = [&](int n, float* out) {
-            if (n <= 0) return;
-            rm.c0[rm.n] = c; rm.c1[rm.n] = c + n; rm.out[rm.n] = out; ++rm.n; c += n;
-        };
-        range(cfg.n_cross * D, grads + m->cn_w);       // partial layout: [cn_w | cn_b | lin_w | lin_b] (k_rowwise_bwd)
-        range(cfg.n_cross * D, grads + m->cn_b);
-        range(D, grads + m->lin_w);
-        range(1, grads + m->lin_b);
-        LAUNCH(k_reduce_tiles_multi, dim3(cdiv(c, 32)), dim3(256), rm);
+        RowwiseFinP rf = {};
+        rf.part = ws + x.w.rw_part; rf.ld = rb.part_ld; rf.cn_w = P + m->cn_w; rf.cn_b = P + m->cn_b;
+        rf.g_cn_w = grads + m->cn_w; rf.g_cn_b = grads + m->cn_b; rf.g_lin_w = grads + m->lin_w; rf.g_lin_b = grads + m->lin_b;
+        rf.D = D; rf.n_cross = cfg.n_cross; rf.r = x.r;
+        switch (cfg.n_cross) {
+            case 0: LAUNCH(k_rowwise_finish<0>, dim3(cdiv(D, 8)), dim3(256), rf); break;
+            case 1: LAUNCH(k_rowwise_finish<1>, dim3(cdiv(D, 8)), dim3(256), rf); break;
+            case 2: LAUNCH(k_rowwise_finish<2>, dim3(cdiv(D, 8)), dim3(256), rf); break;
+            case 3: LAUNCH(k_rowwise_finish<3>, dim3(cdiv(D, 8)), dim3(256), rf); break;
+            default: LAUNCH(k_rowwise_finish<4>, dim3(cdiv(D, 8)), dim3(256), rf); break;
+        }
     }
-    LAUNCH(k_seg_reduce, dim3(c->n_seg, cdiv(E, 16)), dim3(256), ws + x.w.dgrp_part, (int64_t)E, E, ws + x.w.grp, SUB, x.r);
+    LAUNCH(k_seg_reduce, dim3(c->n_seg, cdiv(E, 16)), dim3(256), ws + x.w.dgrp_part, (int64_t)E, E, ws + x.w.grp, RWB_SUB, x.r);
     LAUNCH(k_grp_bwd, dim3(1), dim3(256), ws + x.w.grp, grads + m->group_emb, cfg.n_tower[0], E, x.r, x.mp);
     x.st = main_st;
     // de_out is complete on the main stream here; the parameter gradients complete on the side stream.
@@ -581,7 +625,8 @@ extern "C" int aread_mlp_forward(const aread_model* m, const aread_mlp_call* c, 
     float* ws = x.ws;
     const int in = m->mlp_in, nl = m->experts.n_layers, last = m->h_last;
     LAUNCH(k_pad_rows, dim3(cdiv(x.rows * in, 256)), dim3(256), xin, (int64_t)in, ws + x.w.In[0], (int64_t)in, in, c->B, x.rows);
-    if (c->train && m->cfg.precision == 1) TRY(transpose_weights(x));      // for the split-bf16 dgrad of aread_mlp_backward
+    if (m->cfg.precision == 1) TRY(prepare_wimg(x, 0));
+    if (c->train && m->cfg.precision == 1) { TRY(transpose_weights(x)); TRY(prepare_wimg(x, 1)); }   // for the dgrad of aread_mlp_backward
     TRY(stack_fwd(x, m->experts, x.w.ex, ws + x.w.In[0], -1));
     const float* act = ws + x.w.ex[nl - 1].Act;
     if (m->mlp_out_layer) {

@@ -528,11 +528,24 @@ __global__ __launch_bounds__(256) void k_mix0_bwd(const Mix0BwdP p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// row-wise trunk backward: cross network, linear term, gate input.  de_out += ...; per-tile partials
-// of the parameter gradients (dw_i, db_i, dw_lin, db_lin) and of the group-embedding gradient.
-// One workgroup per tile; wave w walks rows w, w+4, ...
-// part layout per tile: [n_cross][D] dw | [n_cross][D] db | [D] dw_lin | 1 db_lin
+// row-wise trunk backward: cross network (layer.py:517-537), linear term, gate input.
+//
+// With c_i = e (1 + X_i) + B_i  (X_i = sum_{j<i} x_j.w_j saved by the forward, B_i = sum_{j<i} b_j) the whole backward of
+// a row collapses onto a handful of per-row SCALARS:
+//     ds_i = dcn.e + sum_{j>i} ds_j (w_j.e)          (three dot products per row, one interleaved reduction)
+//     u_i  = ds_i (1 + X_i),   alpha = 1 + sum_i xw_i
+//     de  += alpha dcn + sum_i u_i w_i + dl w_lin + deg (+ dq on the domain field's columns)
+// and the parameter gradients are column sums over the rows:
+//     dw_i = sum_r u_i e + B_i sum_r ds_i,   db_i = sum_r dcn + sum_{j>i} w_j sum_r ds_j,   dw_lin = sum_r dl e,  db_lin = sum_r dl
+// so a workgroup only accumulates  EU_i = sum u_i e (NC vectors), EL = sum dl e, DC = sum dcn  and NC+1 scalars; the
+// finishing kernel (k_rowwise_finish) applies the B_i / w_j terms once.  No recomputation of c_i, a third of the
+// accumulator registers of a literal transcription, every load of a row independent of every other.
+//
+// Half a wave (32 lanes) per row, lane hl owns float4 chunks hl, hl+32, ...; a workgroup covers RWB_ROWS rows.
+// part layout per workgroup: [NC][D] EU | [D] EL | [D] DC | NC x sum ds_i | sum dl
 // ------------------------------------------------------------------------------------------------
+#define RWB_ROWS 32
+#define RWB_SUB (TILE_M / RWB_ROWS)
 struct RowwiseBwdP {
     const float* e; const float* xw; const float* dcn; const float* dlin; const float* dq; const float* deg;
     const float* lin_w; const float* cn_w; const float* cn_b;
@@ -541,157 +554,218 @@ struct RowwiseBwdP {
     RowsP r;
 };
 
-template <int NC, int RW_MAXV>
+template <int NC, int NV>
 __global__ __launch_bounds__(256) void k_rowwise_bwd(const RowwiseBwdP p) {
-    __shared__ float4 s_red[4][256];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tile = blockIdx.x / SUB, r_lo = (blockIdx.x % SUB) * SUB_ROWS;
+    __shared__ float4 s_red[4][NV][32];
+    __shared__ float s_sc[8][8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane & 31, hw = wave * 2 + (lane >> 5);
+    const int tile = blockIdx.x / RWB_SUB, r_lo = (blockIdx.x % RWB_SUB) * RWB_ROWS;
     if (p.r.tile_seg[tile] < 0) return;
     const int nvalid = p.r.tile_valid[tile];
-    const int r_hi = (r_lo + SUB_ROWS < nvalid) ? r_lo + SUB_ROWS : nvalid;
+    const int r_hi = (r_lo + RWB_ROWS < nvalid) ? r_lo + RWB_ROWS : nvalid;
     const int d4 = p.D >> 2;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     constexpr int NCA = NC > 0 ? NC : 1;
-    float4 adw[NCA][RW_MAXV], adb[NCA][RW_MAXV], adl[RW_MAXV];
-    float adbl = 0.f;
+    float4 eu[NCA][NV], el[NV], dcs[NV];
+    float sds[NCA], sdl = 0.f;
 #pragma unroll
-    for (int v = 0; v < RW_MAXV; ++v) {
-        adl[v] = zero;
+    for (int i = 0; i < NCA; ++i) sds[i] = 0.f;
 #pragma unroll
-        for (int i = 0; i < NCA; ++i) { adw[i][v] = zero; adb[i][v] = zero; }
+    for (int v = 0; v < NV; ++v) {
+        el[v] = zero; dcs[v] = zero;
+#pragma unroll
+        for (int i = 0; i < NCA; ++i) eu[i][v] = zero;
     }
-    for (int rr = r_lo + wave; rr < r_hi; rr += 4) {
+    const int dom_c0 = p.dom_field * p.E, dom_c1 = dom_c0 + p.E;
+    for (int rr = r_lo + hw; rr < r_lo + RWB_ROWS; rr += 8) {
+        const bool live = rr < r_hi;                   // (the whole half-wave agrees; dead rows only keep the shuffles uniform)
         const int64_t row = (int64_t)tile * TILE_M + rr;
-        float4 e[RW_MAXV], c[NCA][RW_MAXV], dc[RW_MAXV], de[RW_MAXV];
+        float4 e[NV], dc[NV], dg[NV], o[NV];
         const float4* e4 = (const float4*)(p.e + row * p.D);
         const float4* g4 = (const float4*)(p.dcn + row * p.D);
+        const float4* q4 = (const float4*)(p.deg + row * p.D);
+        float4* o4 = (float4*)(p.de + row * p.D);
 #pragma unroll
-        for (int v = 0; v < RW_MAXV; ++v) {
-            const int ch = lane + 64 * v;
-            e[v] = ch < d4 ? e4[ch] : zero;
-            dc[v] = ch < d4 ? g4[ch] : zero;
-            de[v] = zero;
-            c[0][v] = e[v];
+        for (int v = 0; v < NV; ++v) {
+            const int ch = hl + 32 * v;
+            const bool on = live && ch < d4;
+            e[v] = on ? e4[ch] : zero;
+            dc[v] = on ? g4[ch] : zero;
+            dg[v] = on ? q4[ch] : zero;
+            o[v] = on ? o4[ch] : zero;
         }
-        // recompute c_1 .. c_{n-1} from the saved x.w scalars
+        float xw[NCA];
 #pragma unroll
-        for (int i = 0; i + 1 < NC; ++i) {
-            {
-                const float xw = p.xw[(int64_t)i * p.rows + row];
-                const float4* b4 = (const float4*)(p.cn_b + (int64_t)i * p.D);
-#pragma unroll
-                for (int v = 0; v < RW_MAXV; ++v) {
-                    const int ch = lane + 64 * v;
-                    if (ch < d4) {
-                        const float4 b = b4[ch];
-                        c[i + 1][v].x = e[v].x * xw + b.x + c[i][v].x;
-                        c[i + 1][v].y = e[v].y * xw + b.y + c[i][v].y;
-                        c[i + 1][v].z = e[v].z * xw + b.z + c[i][v].z;
-                        c[i + 1][v].w = e[v].w * xw + b.w + c[i][v].w;
-                    } else c[i + 1][v] = zero;
-                }
-            }
-        }
-        // ds_i = dc_i . e with dc_i = dcn + sum_{j>i} w_j ds_j  =>  ds_i = (dcn . e) + sum_{j>i} ds_j (w_j . e): the row's
-        // dot products are independent of the recursion, so one interleaved wave reduction replaces NC chained ones
-        float dots[NCA];                       // [0] = dcn . e, [j] = w_j . e (j >= 1)
+        for (int i = 0; i < NC; ++i) xw[i] = live ? p.xw[(int64_t)i * p.rows + row] : 0.f;
+        const float dl = live ? p.dlin[row] : 0.f;
+        float dots[NCA];                               // [0] = dcn.e, [j] = w_j.e (j >= 1)
 #pragma unroll
         for (int j = 0; j < NCA; ++j) dots[j] = 0.f;
 #pragma unroll
-        for (int v = 0; v < RW_MAXV; ++v) {
-            const int ch = lane + 64 * v;
+        for (int v = 0; v < NV; ++v) {
+            const int ch = hl + 32 * v;
             dots[0] += dot4(dc[v], e[v]);
 #pragma unroll
             for (int j = 1; j < NC; ++j)
                 if (ch < d4) dots[j] += dot4(((const float4*)(p.cn_w + (int64_t)j * p.D))[ch], e[v]);
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
+        for (int ofs = 16; ofs > 0; ofs >>= 1) {
 #pragma unroll
-            for (int j = 0; j < NCA; ++j) dots[j] += __shfl_xor(dots[j], o);
+            for (int j = 0; j < NCA; ++j) dots[j] += __shfl_xor(dots[j], ofs);
         }
-        float dsv[NCA];
+        float ds[NCA], u[NCA], alpha = 1.f, X = 0.f;
 #pragma unroll
         for (int i = NC - 1; i >= 0; --i) {
             float t = dots[0];
 #pragma unroll
-            for (int j = NC - 1; j > i; --j) t += dsv[j] * dots[j];
-            dsv[i] = t;
+            for (int j = NC - 1; j > i; --j) t += ds[j] * dots[j];
+            ds[i] = t;
         }
 #pragma unroll
-        for (int i = NC - 1; i >= 0; --i) {
-            {
-                const float xw = p.xw[(int64_t)i * p.rows + row];
-                const float4* w4 = (const float4*)(p.cn_w + (int64_t)i * p.D);
-                const float ds = dsv[i];
-#pragma unroll
-                for (int v = 0; v < RW_MAXV; ++v) {
-                    const int ch = lane + 64 * v;
-                    if (ch < d4) {
-                        const float4 w = w4[ch];
-                        de[v].x += dc[v].x * xw; de[v].y += dc[v].y * xw; de[v].z += dc[v].z * xw; de[v].w += dc[v].w * xw;
-                        adb[i][v].x += dc[v].x; adb[i][v].y += dc[v].y; adb[i][v].z += dc[v].z; adb[i][v].w += dc[v].w;
-                        adw[i][v].x += ds * c[i][v].x; adw[i][v].y += ds * c[i][v].y;
-                        adw[i][v].z += ds * c[i][v].z; adw[i][v].w += ds * c[i][v].w;
-                        dc[v].x += w.x * ds; dc[v].y += w.y * ds; dc[v].z += w.z * ds; dc[v].w += w.w * ds;
-                    }
-                }
-            }
+        for (int i = 0; i < NC; ++i) {
+            u[i] = ds[i] * (1.f + X);
+            X += xw[i];
+            alpha += xw[i];
+            sds[i] += ds[i];
         }
-        const float dl = p.dlin[row];
-        adbl += dl;
-        float4* o4 = (float4*)(p.de + row * p.D);
+        sdl += dl;
 #pragma unroll
-        for (int v = 0; v < RW_MAXV; ++v) {
-            const int ch = lane + 64 * v;
+        for (int v = 0; v < NV; ++v) {
+            const int ch = hl + 32 * v;
             if (ch < d4) {
                 const float4 wl = ((const float4*)p.lin_w)[ch];
-                float4 t = o4[ch];
-                const float4 gq = ((const float4*)(p.deg + row * p.D))[ch];       // MMoE-gate part of dE (side stream)
-                t.x += gq.x; t.y += gq.y; t.z += gq.z; t.w += gq.w;
-                t.x += de[v].x + dc[v].x + dl * wl.x; t.y += de[v].y + dc[v].y + dl * wl.y;
-                t.z += de[v].z + dc[v].z + dl * wl.z; t.w += de[v].w + dc[v].w + dl * wl.w;
-                // domain-embedding part of the gate input
+                float4 t = o[v];
+                t.x += dg[v].x + alpha * dc[v].x + dl * wl.x; t.y += dg[v].y + alpha * dc[v].y + dl * wl.y;
+                t.z += dg[v].z + alpha * dc[v].z + dl * wl.z; t.w += dg[v].w + alpha * dc[v].w + dl * wl.w;
+#pragma unroll
+                for (int i = 0; i < NC; ++i) {
+                    const float4 w = ((const float4*)(p.cn_w + (int64_t)i * p.D))[ch];
+                    t.x += u[i] * w.x; t.y += u[i] * w.y; t.z += u[i] * w.z; t.w += u[i] * w.w;
+                    eu[i][v].x += u[i] * e[v].x; eu[i][v].y += u[i] * e[v].y; eu[i][v].z += u[i] * e[v].z; eu[i][v].w += u[i] * e[v].w;
+                }
                 const int col = ch * 4;
-                if (col >= p.dom_field * p.E && col < (p.dom_field + 1) * p.E) {
-                    const float4 dqv = *(const float4*)(p.dq + row * 2 * p.E + (col - p.dom_field * p.E));
+                if (col >= dom_c0 && col < dom_c1 && live) {       // domain-embedding part of the gate input
+                    const float4 dqv = *(const float4*)(p.dq + row * 2 * p.E + (col - dom_c0));
                     t.x += dqv.x; t.y += dqv.y; t.z += dqv.z; t.w += dqv.w;
                 }
-                o4[ch] = t;
-                adl[v].x += dl * e[v].x; adl[v].y += dl * e[v].y; adl[v].z += dl * e[v].z; adl[v].w += dl * e[v].w;
+                if (live) o4[ch] = t;
+                el[v].x += dl * e[v].x; el[v].y += dl * e[v].y; el[v].z += dl * e[v].z; el[v].w += dl * e[v].w;
+                dcs[v].x += dc[v].x; dcs[v].y += dc[v].y; dcs[v].z += dc[v].z; dcs[v].w += dc[v].w;
             }
         }
     }
-    // ---- combine the four waves through LDS, vector by vector, and write the tile partial ----------
+    // ---- combine the eight half-waves in a fixed order and write the workgroup's partial -------------------
     float* out = p.part + (int64_t)blockIdx.x * p.part_ld;
-    auto flush = [&](float4 (&acc)[RW_MAXV], int64_t off) {
-        for (int v = 0; v < RW_MAXV; ++v) {
-            const int ch = lane + 64 * v;
-            __syncthreads();
-            if (ch < d4) s_red[wave][lane] = acc[v];
-            __syncthreads();
-            if (wave == 0 && ch < d4) {
-                float4 t = s_red[0][lane];
-                for (int w = 1; w < 4; ++w) { t.x += s_red[w][lane].x; t.y += s_red[w][lane].y; t.z += s_red[w][lane].z; t.w += s_red[w][lane].w; }
+    auto flush = [&](float4 (&acc)[NV], int64_t off) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            float4 a = acc[v];
+            a.x += __shfl_xor(a.x, 32); a.y += __shfl_xor(a.y, 32); a.z += __shfl_xor(a.z, 32); a.w += __shfl_xor(a.w, 32);
+            if (lane < 32) s_red[wave][v][hl] = a;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < NV * 32; i += 256) {
+            const int v = i >> 5, l = i & 31, ch = l + 32 * v;
+            if (ch < d4) {
+                float4 t = s_red[0][v][l];
+#pragma unroll
+                for (int w = 1; w < 4; ++w) { const float4 b = s_red[w][v][l]; t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w; }
                 *(float4*)(out + off + ch * 4) = t;
             }
         }
+        __syncthreads();
     };
 #pragma unroll
-    for (int i = 0; i < NC; ++i) {
-        flush(adw[i], (int64_t)i * p.D);
-        flush(adb[i], (int64_t)(NC + i) * p.D);
+    for (int i = 0; i < NC; ++i) flush(eu[i], (int64_t)i * p.D);
+    flush(el, (int64_t)NC * p.D);
+    flush(dcs, (int64_t)(NC + 1) * p.D);
+    if (hl == 0) {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) s_sc[hw][i] = sds[i];
+        s_sc[hw][NC] = sdl;
     }
-    flush(adl, (int64_t)2 * p.n_cross * p.D);
     __syncthreads();
-    if (lane == 0) s_red[wave][0].x = adbl;
-    __syncthreads();
-    if (threadIdx.x == 0) out[(int64_t)(2 * p.n_cross + 1) * p.D] = (s_red[0][0].x + s_red[1][0].x) + (s_red[2][0].x + s_red[3][0].x);
+    if (threadIdx.x <= NC) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += s_sc[k][threadIdx.x];
+        out[(int64_t)(NC + 2) * p.D + threadIdx.x] = t;
+    }
     // group-embedding gradient partial: sum over valid rows of dq[:, E:2E]
     for (int cidx = threadIdx.x; cidx < p.E; cidx += 256) {
         float s = 0.f;
         for (int rr = r_lo; rr < r_hi; ++rr) s += p.dq[((int64_t)tile * TILE_M + rr) * 2 * p.E + p.E + cidx];
         p.dgrp_part[(int64_t)blockIdx.x * p.E + cidx] = s;
+    }
+}
+
+// parameter gradients of the row-wise trunk from the workgroup partials (fixed order: 8 interleaved slot groups, then
+// combined): dw_i = EU_i + B_i S_i, db_i = DC + sum_{j>i} w_j S_j, dw_lin = EL, db_lin = SL.  Block = 32 columns.
+struct RowwiseFinP {
+    const float* part; int64_t ld; const float* cn_w; const float* cn_b;
+    float* g_cn_w; float* g_cn_b; float* g_lin_w; float* g_lin_b;
+    int D, n_cross;
+    RowsP r;
+};
+template <int NC>
+__global__ __launch_bounds__(256) void k_rowwise_finish(const RowwiseFinP p) {
+    // block = 8 columns x 32 interleaved slot groups (the partial list is short and wide: spread the slots over the
+    // lanes so that a thread sees ~10 slots, loaded four at a time)
+    constexpr int Q = NC + 2;
+    __shared__ float s_acc[32][Q][9];
+    __shared__ float s_sc[32][NC + 1];
+    const int cl = threadIdx.x & 7, tg = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;
+    const int n_slots = p.r.hdr[PLAN_NTILES] * RWB_SUB;
+    const bool col = c < p.D;
+    float a[Q], sc[NC + 1];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) a[q] = 0.f;
+#pragma unroll
+    for (int q = 0; q <= NC; ++q) sc[q] = 0.f;
+#pragma unroll 4
+    for (int t = tg; t < n_slots; t += 32) {
+        const float* pp = p.part + (int64_t)t * p.ld;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) a[q] += col ? pp[(int64_t)q * p.D + c] : 0.f;
+#pragma unroll
+        for (int q = 0; q <= NC; ++q) sc[q] += pp[(int64_t)Q * p.D + q];
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) s_acc[tg][q][cl] = a[q];
+    if (cl == 0)
+#pragma unroll
+        for (int q = 0; q <= NC; ++q) s_sc[tg][q] = sc[q];
+    __syncthreads();
+    if (tg == 0 && col) {
+        float tot[Q], S[NC + 1];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) t += s_acc[k][q][cl];
+            tot[q] = t;
+        }
+#pragma unroll
+        for (int q = 0; q <= NC; ++q) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) t += s_sc[k][q];
+            S[q] = t;
+        }
+        float Bi = 0.f;                                   // B_i = sum_{j<i} b_j
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            p.g_cn_w[(int64_t)i * p.D + c] = tot[i] + Bi * S[i];
+            Bi += p.cn_b[(int64_t)i * p.D + c];
+            float db = tot[NC + 1];
+#pragma unroll
+            for (int j = i + 1; j < NC; ++j) db += p.cn_w[(int64_t)j * p.D + c] * S[j];
+            p.g_cn_b[(int64_t)i * p.D + c] = db;
+        }
+        p.g_lin_w[c] = tot[NC];
+        if (c == 0) p.g_lin_b[0] = S[NC];
     }
 }
 

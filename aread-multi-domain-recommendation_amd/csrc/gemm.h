@@ -39,6 +39,7 @@ struct GemmP {
     int gate_axis;                           // 0 none, 1 = M, 2 = K
     // BatchNorm statistics epilogue (forward): per m-tile, per column: (mean, M2) over the valid rows
     float* stat_part; int64_t stat_ld;       // stat_part[(tile_m*stat_ld + g*N + n)*2 + {0,1}]
+    int dbg;                                 // timing-only ablation bits of k_gemm_bf3w (tools/gemm_wide_bench.py); 0 in the product
 };
 
 // LDS image of an operand tile.  KC operands: [rows][BK+2] (k contiguous, as in global memory).

@@ -9,37 +9,51 @@
 
 typedef float l2_f4 __attribute__((ext_vector_type(4)));
 
+// The pass is cut into L2_BLOCKS "virtual blocks" (one partial sum each, a grid-stride sweep each); a launch of fewer
+// real workgroups lets every workgroup walk several virtual blocks.  Result and partial sums are therefore bitwise
+// independent of the launch width, which is the throttle of aread_l2_table_throttled.
 __global__ __launch_bounds__(L2_THREADS) void k_l2_table(const float* __restrict__ w, int64_t n, float gscale,
                                                          float* __restrict__ grad, float* __restrict__ partial) {
     const int64_t n4 = n >> 2;
     const float4* w4 = (const float4*)w;
     float4* g4 = (float4*)grad;
-    float acc = 0.f;
-    const int64_t stride = (int64_t)gridDim.x * L2_THREADS;
-    for (int64_t i = (int64_t)blockIdx.x * L2_THREADS + threadIdx.x; i < n4; i += stride) {
-        const l2_f4 v = __builtin_nontemporal_load((const l2_f4*)(w4 + i));       // streamed once: bypass L2/MALL retention
-        acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-        if (grad) {
-            const l2_f4 g = {gscale * v.x, gscale * v.y, gscale * v.z, gscale * v.w};
-            __builtin_nontemporal_store(g, (l2_f4*)(g4 + i));
-        }
-    }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {             // scalar tail
-        const int64_t i = (n4 << 2) + threadIdx.x;
-        const float v = w[i];
-        acc += v * v;
-        if (grad) grad[i] = gscale * v;
-    }
-    if (!partial) return;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    const int64_t stride = (int64_t)L2_BLOCKS * L2_THREADS;
     __shared__ float s[L2_THREADS / WAVE];
-    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float t = 0.f;
-        for (int i = 0; i < L2_THREADS / WAVE; ++i) t += s[i];
-        partial[blockIdx.x] = t;
+    for (int vb = blockIdx.x; vb < L2_BLOCKS; vb += gridDim.x) {
+        float acc = 0.f;
+        int64_t i = (int64_t)vb * L2_THREADS + threadIdx.x;
+        for (; i + 3 * stride < n4; i += 4 * stride) {           // four independent 16-byte loads in flight per lane
+            l2_f4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load((const l2_f4*)(w4 + i + u * stride));   // streamed once
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc += v[u].x * v[u].x + v[u].y * v[u].y + v[u].z * v[u].z + v[u].w * v[u].w;
+                if (grad) __builtin_nontemporal_store(v[u] * gscale, (l2_f4*)(g4 + i + u * stride));
+            }
+        }
+        for (; i < n4; i += stride) {
+            const l2_f4 v = __builtin_nontemporal_load((const l2_f4*)(w4 + i));
+            acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            if (grad) __builtin_nontemporal_store(v * gscale, (l2_f4*)(g4 + i));
+        }
+        if (vb == 0 && threadIdx.x < (n & 3)) {                 // scalar tail
+            const int64_t i = (n4 << 2) + threadIdx.x;
+            const float v = w[i];
+            acc += v * v;
+            if (grad) grad[i] = gscale * v;
+        }
+        if (!partial) continue;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = 0.f;
+            for (int i = 0; i < L2_THREADS / WAVE; ++i) t += s[i];
+            partial[vb] = t;
+        }
     }
 }
 
@@ -62,15 +76,22 @@ __global__ __launch_bounds__(256) void k_l2_finish(const float* __restrict__ par
 
 extern "C" int aread_l2_partials(void) { return L2_BLOCKS; }
 
-extern "C" int aread_l2_table(const float* w, int64_t n, float l2, float grad_scale, float* grad, float* partial,
-                              void* stream) {
+extern "C" int aread_l2_table_throttled(const float* w, int64_t n, float l2, float grad_scale, float* grad, float* partial,
+                                        int max_workgroups, void* stream) {
     AR_CHECK_ARG(w != nullptr && n > 0, "aread_l2_table: empty input");
     AR_CHECK_ARG(((uintptr_t)w & 15) == 0 && ((uintptr_t)grad & 15) == 0, "aread_l2_table: 16-byte alignment");
     AR_CHECK_ARG(grad || partial, "aread_l2_table: nothing to do");
-    hipLaunchKernelGGL(k_l2_table, dim3(L2_BLOCKS), dim3(L2_THREADS), 0, (hipStream_t)stream, w, n,
+    int blocks = L2_BLOCKS;
+    if (max_workgroups > 0 && max_workgroups < blocks) blocks = max_workgroups;
+    hipLaunchKernelGGL(k_l2_table, dim3(blocks), dim3(L2_THREADS), 0, (hipStream_t)stream, w, n,
                        2.0f * l2 * grad_scale, grad, partial);
     AR_LAUNCH_CHECK();
     return AREAD_OK;
+}
+
+extern "C" int aread_l2_table(const float* w, int64_t n, float l2, float grad_scale, float* grad, float* partial,
+                              void* stream) {
+    return aread_l2_table_throttled(w, n, l2, grad_scale, grad, partial, 0, stream);
 }
 
 extern "C" int aread_l2_finish(const float* partial, int n_partial, float l2, float* loss_out, int accumulate,

@@ -199,6 +199,13 @@ static int64_t take(int64_t* o, int64_t n) {
     return r;
 }
 
+// floats taken by the pre-tiled split-bf16 image of a weight operand (gemm_wide.h: 32*NF-row tiles, 32-wide k-steps, hi + lo)
+static int64_t wimg_floats(int G, int N, int K) {
+    const int nf = N <= 64 ? 2 : (((N + 95) / 96 * 96 < (N + 127) / 128 * 128) ? 3 : 4);
+    const int64_t tn = 32 * nf;
+    return (int64_t)G * ((N + tn - 1) / tn) * ((K + 31) / 32) * 2 * tn * 32 / 2;
+}
+
 static void layer_ws(const LayerL& L, int64_t rows, int64_t tiles, int n_seg, LayerWs* w, int64_t* o) {
     w->H = take(o, rows * L.ncols);
     w->Act = take(o, rows * L.ncols);
@@ -211,6 +218,10 @@ static void layer_ws(const LayerL& L, int64_t rows, int64_t tiles, int n_seg, La
     w->s12 = take(o, (int64_t)n_seg * L.ncols * 2);
     w->cpart = take(o, tiles * L.ncols);
     w->wT = take(o, (int64_t)L.ncols * L.in_dim);
+    const bool one = (L.in_gs == 0 && L.G > 1) || L.G == 1;          // the groups share their input: one GEMM over all columns
+    const int G = one ? 1 : L.G, N = one ? L.ncols : L.out_dim;
+    w->wimg_f = take(o, wimg_floats(G, N, L.in_dim));
+    w->wimg_d = take(o, wimg_floats(G, L.in_dim, N));
 }
 
 void ws_layout(const aread_model* m, int64_t B, int n_seg, WsLayout* w) {

@@ -24,6 +24,7 @@ struct LayerL {              // one (grouped) Linear+BatchNorm layer of an MLP s
 struct LayerWs {             // workspace of one layer (float offsets)
     int64_t H, Act, dAct, part, mean, rstd, var, bpart, s12, cpart;
     int64_t wT;              // transposed weights [G][in][out] (split-bf16 dgrad wants k-contiguous operands)
+    int64_t wimg_f, wimg_d;  // pre-tiled split-bf16 weight images for the wide GEMM (gemm_wide.h): forward, dgrad view
 };
 
 struct StackL {

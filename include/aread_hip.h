@@ -85,7 +85,7 @@ int aread_embed_fwd(const int32_t* x, int64_t B, int f_in, const int32_t* offset
 
 /* Backward of the lookup (autograd of layer.py:166-178): table_grad[g] += c * dout row, c = 1 for
  * one-hot fields, 1/seq_len for 'mean' history slots.  Deterministic: contributions are radix-sorted
- * by table row and summed in a fixed order by a wavefront segmented reduction; no float atomics.
+ * by table row (hand-written LSD sort) and summed in a fixed order by a segmented reduction; no float atomics.
  * table_grad must already hold the value to accumulate onto (zeros, or the dense L2 term).
  * sample_row (optional): row of dout that holds sample b (the plan's sample_row array); NULL = b.
  * ws: workspace of aread_embed_bwd_ws_bytes(B, f_in, E) bytes. */
@@ -131,6 +131,11 @@ int aread_route_build(const int32_t* x, int64_t B, int f_in, const int32_t* offs
 int aread_l2_partials(void);
 int aread_l2_table(const float* w, int64_t n, float l2, float grad_scale, float* grad,
                    float* partial, void* stream);
+/* The same pass on at most max_workgroups workgroups (0 = full width): a background sweep that leaves HBM bandwidth and
+ * compute units to the kernels of the critical path (the fused step runs it beside the forward).  Bitwise the same
+ * gradient and partial sums as aread_l2_table at any width. */
+int aread_l2_table_throttled(const float* w, int64_t n, float l2, float grad_scale, float* grad,
+                             float* partial, int max_workgroups, void* stream);
 int aread_l2_finish(const float* partial, int n_partial, float l2, float* loss_out, int accumulate,
                     void* stream);
 
@@ -281,6 +286,22 @@ int aread_model_l2_coef(const aread_model* m, float* coef_host);
 int64_t aread_debug_ws_offset(const aread_model* m, int64_t B, int n_seg, const char* name);
 int aread_l2_dense(const float* params, const float* coef, int64_t n, float* grads, float* loss_out,
                    int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Wide split-bf16 GEMM (csrc/gemm_wide.h): the kernel behind the expert / tower Linear layers of aread_forward /
+ * aread_backward (MultiLayerPerceptron, model/layer.py:203-229; aread.py:150-151), exposed for tests and bench.py.
+ *   C[g][m][n] (+)= sum_k A[g*a_gs + m*lda + k] * W(g, n, k) (+ bias[g*bias_gs + n]),  hi*hi + hi*lo + lo*hi on
+ *   v_mfma_f32_16x16x32_bf16 with fp32 accumulation, 128-row tiles.
+ * The weight operand is a pre-tiled split-bf16 image written once per parameter update by aread_wimg_prepare from
+ * W(g, n, k) = W[g*w_gs + n*w_sn + k*w_sk] (forward: w_sn = K, w_sk = 1; dgrad view of a [out, in] weight: w_sn = 1,
+ * w_sk = in); img: aread_wimg_bytes(N, K, G) bytes, 256-byte aligned.  N, lda, ldc and the group strides must be
+ * multiples of 4.
+ * ------------------------------------------------------------------------------------------- */
+int64_t aread_wimg_bytes(int N, int K, int G);
+int aread_wimg_prepare(const float* W, int64_t w_gs, int64_t w_sn, int64_t w_sk, int N, int K, int G, void* img,
+                       void* stream);
+int aread_gemm_bf16x3_wide(const float* A, int64_t lda, int64_t a_gs, const void* img, float* C, int64_t ldc, int64_t c_gs,
+                           const float* bias, int64_t bias_gs, int M, int N, int K, int G, int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused optimizer.  torch.optim.Adam as the reference configures it (run.py:830-831: lr 1e-3,
