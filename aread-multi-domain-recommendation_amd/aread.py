@@ -245,6 +245,7 @@ class AREAD(HempMixin, nn.Module):
         self.drop_seed_base = 0
         import os
         self.l2_pass_workgroups = int(os.environ.get("AREAD_L2_WG", "0"))   # width of the table L2 sweep inside the fused step
+        self.l2_pass_early = os.environ.get("AREAD_L2_EARLY", "0") == "1"    # A/B: the sweep right after the row plan (round 1)
         self.drop_seed = None          # set to an int to pin the dropout stream (tests)
         self._register_state_dict_hook(AREAD._sd_hook)
         self._register_load_state_dict_pre_hook(self._load_hook)
@@ -589,26 +590,32 @@ class AREAD(HempMixin, nn.Module):
         # on the side stream, so the main stream never waits for the host.
         if plan is None:                               # first on the main stream: everything else waits for it, and it is
             plan = RowPlan(x, self.domain_idx if n_seg > 1 else -1, n_seg)     # latency-bound (slow next to the HBM-saturating L2 pass)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            if not table_pass:
-                bufs["reg"].zero_()
-            elif with_reg:
-                # a background sweep on a few workgroups: the 356 MB stream would otherwise take the HBM bandwidth away
-                # from the latency-bound head of the critical path (row plan, gather); it has the whole forward to finish
-                L.check(lib.aread_l2_table_throttled(L.ptr(table), table.numel(), self.l2_reg_embedding, 1.0, L.ptr(gtable),
-                                                     L.ptr(part), self.l2_pass_workgroups, L.stream()))
-                L.check(lib.aread_l2_finish(L.ptr(part), part.numel(), self.l2_reg_embedding, L.ptr(bufs["reg"]), 0,
-                                            L.stream()))
-            else:
-                gtable.zero_()
-                bufs["reg"].zero_()
+        # The table L2 pass (356 MB of HBM traffic, needed only by the embedding reduction at the very end) goes on the side
+        # stream BEHIND the forward (AREAD_L2_EARLY=1: right after the row plan, as in round 1): next to the latency-bound head
+        # of the step (gather, first GEMM) it cost those kernels 2-3x their isolated time.
+        def l2_pass():
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                if not table_pass:
+                    bufs["reg"].zero_()
+                elif with_reg:
+                    L.check(lib.aread_l2_table_throttled(L.ptr(table), table.numel(), self.l2_reg_embedding, 1.0, L.ptr(gtable),
+                                                         L.ptr(part), self.l2_pass_workgroups, L.stream()))
+                    L.check(lib.aread_l2_finish(L.ptr(part), part.numel(), self.l2_reg_embedding, L.ptr(bufs["reg"]), 0,
+                                                L.stream()))
+                else:
+                    gtable.zero_()
+                    bufs["reg"].zero_()
+        if self.l2_pass_early:
+            l2_pass()
         if presort:
             plan_ready = torch.cuda.Event()
             plan_ready.record(main)
         st, gate = self._run(x, 0, n_seg, domain_i, masks_dev, want_gates, y=y, seg_weight=seg_weight,
                              loss_out=bufs["loss"], ws=bufs["ws"], probs=bufs["probs"], e=bufs["e"], plan=plan,
                              e_ready=e_ready, async_fwd=True)
+        if not self.l2_pass_early:
+            l2_pass()
         if presort:
             side.wait_event(plan_ready)
             with torch.cuda.stream(side):
@@ -644,14 +651,11 @@ class AREAD(HempMixin, nn.Module):
         besides the row plan (run.py:668-680 without the optimizer).  y: float32 [B] on the device.
         Returns the device scalar loss = sum_d w_d*bag_d + reg."""
         st = self.step_local(x, y, bufs, masks_dev, domain_i, seg_weight, with_reg, True, want_gates, presort=True)
-        # tail: the segmented reduction into the table gradient on the main stream, concurrently (side stream) the join
-        # with the library's parameter-gradient reductions and the dense L2 term
-        main, side = torch.cuda.current_stream(), self._side_stream(x.device)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            self.step_finish(bufs)
+        # tail, all on the main stream (every cross-stream hop costs more than the few small kernels it could overlap): the
+        # segmented reduction into the table gradient, then the join with the library's parameter-gradient reductions
+        # (long finished by then) and the dense L2 term
         self.embedding.reduce_sorted(x, bufs["de"], bufs["gtable"])
-        main.wait_stream(side)
+        self.step_finish(bufs)
         torch.add(bufs["loss"][:1], bufs["reg"][:1], out=bufs["total"])
         if set_grads:
             for p in self.dense_params:

@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include "dense_bwd_kernels.h"
 #include "gemm_wide.h"
+#include "tower_fused.h"
 
 
 struct Ctx {
@@ -24,6 +25,11 @@ struct Ctx {
     BiasAllP bias;          // layers waiting for the batched bias-gradient reduction
     hipStream_t side;       // fork-join side stream (wgrads, gate logits): work off the critical path
     int ev_next;
+    // weight-gradient GEMMs waiting for the next batch launch on the side stream (flush_wgrads).  A cross-stream fork costs
+    // the host and the command processor far more than a launch (measured: ~20 us per fork-launch pair against ~4 us per
+    // launch, tools/event_cost.py), so the backward forks three times, not once per layer.
+    GemmP pend[MAX_WGRADS];
+    int n_pend;
 };
 
 // side stream waits for everything issued so far on the main stream
@@ -69,6 +75,7 @@ static int make_ctx(const aread_model* m, const aread_call* c, void* stream, Ctx
     x->params = c->params;
     x->splitk.n = 0;
     x->bias.n = 0;
+    x->n_pend = 0;
     TRY0(model_streams_init(m));
     x->side = m->side;
     x->ev_next = 0;
@@ -117,11 +124,15 @@ static int prepare_wimg(Ctx& x, int which) {
     return launch_prep_wimg(a, x.st);
 }
 static int g_wide_mode = -1;      // AREAD_WIDE: 0 = 64-row kernels everywhere (default: measured equal or faster in the step), 1 = wide kernel for the experts, 2 = for every layer
-static bool use_wide(const Ctx& x, const LayerL& L) {
+static bool wide_any() {
     if (g_wide_mode < 0) {
         const char* e = getenv("AREAD_WIDE");
         g_wide_mode = e ? atoi(e) : 0;
     }
+    return g_wide_mode > 0;
+}
+static bool use_wide(const Ctx& x, const LayerL& L) {
+    wide_any();
     if (x.m->cfg.precision != 1 || g_wide_mode == 0) return false;
     return g_wide_mode >= 2 || L.stack == 0;
 }
@@ -197,6 +208,132 @@ static void launch_rowwise_fwd(Ctx& x, const RowwiseP& p) {
     hipLaunchKernelGGL((k_rowwise_fwd<MAXV>), dim3(x.n_tiles * SUB), dim3(256), 0, x.st, p);
 }
 
+// ---- fused tower pyramid (tower_fused.h) -----------------------------------------------------------------------------
+// ---- diagnostics: GPU time stamps of the phases of the main stream (aread_debug_set("phase_events", 1), tools/phase_times.py) ----
+#define N_PHASE_EV 16
+static int g_phase_on = 0;
+static hipEvent_t g_phase_ev[N_PHASE_EV];
+static bool g_phase_init = false, g_phase_rec[N_PHASE_EV] = {};
+static void phase_mark(hipStream_t st, int i) {
+    if (!g_phase_on) return;
+    if (!g_phase_init) { for (int k = 0; k < N_PHASE_EV; ++k) (void)hipEventCreate(&g_phase_ev[k]); g_phase_init = true; }
+    (void)hipEventRecord(g_phase_ev[i], st);
+    g_phase_rec[i] = true;
+}
+extern "C" int aread_debug_phase_times(float* out_ms, int n) {
+    AR_CHECK_ARG(out_ms && g_phase_init, "aread_debug_phase_times: phase events are not enabled");
+    for (int i = 0; i + 1 < N_PHASE_EV && i < n; ++i) {
+        out_ms[i] = -1.f;
+        if (g_phase_rec[i] && g_phase_rec[i + 1] && hipEventQuery(g_phase_ev[i]) == hipSuccess && hipEventQuery(g_phase_ev[i + 1]) == hipSuccess)
+            (void)hipEventElapsedTime(&out_ms[i], g_phase_ev[i], g_phase_ev[i + 1]);
+    }
+    (void)hipGetLastError();
+    return AREAD_OK;
+}
+
+static int g_fused_mode = -1;        // AREAD_FUSED_TOWERS: 0 = layer-by-layer launches (default: measured faster), 1 = fused tower forward
+static int g_n_cu = 0;
+static int g_tf_stamps = 0;     // aread_debug_set("tf_stamps", 1): phase time stamps of k_tower_fwd into the workspace (tools/tf_stamps.py)
+static size_t tower_fwd_lds(const aread_model* m, TFwdP* p) {
+    const aread_model_cfg& c = m->cfg;
+    int max_blk_bytes = 0, max_cols = 0, max_ngate = 0;
+    for (int l = 0; l < c.n_level; ++l) {
+        const int n_src = l == 0 ? c.n_expert : c.n_tower[l - 1];
+        if (c.n_tower[l] * n_src > max_ngate) max_ngate = c.n_tower[l] * n_src;
+        for (int j = 0; j < m->towers[l].n_layers; ++j) {
+            const LayerL& L = m->towers[l].L[j];
+            const int pk = L.in_dim >= 32 ? 4 : L.in_dim / 8, ks = (L.in_dim + 31) / 32;
+            const int bytes = L.G * ks * 2 * pk * 512 * 2;
+            if (bytes > max_blk_bytes) max_blk_bytes = bytes;
+            if (L.ncols > max_cols) max_cols = L.ncols;
+        }
+    }
+    auto up = [](size_t v) { return (v + 1023) & ~(size_t)1023; };
+    size_t o = 0;
+    if (p) p->lds_aimg = (int)o;
+    o = up(o + max_blk_bytes);
+    if (p) p->lds_actf = (int)o;
+    o = up(o + (size_t)TILE_M * max_cols * 4);
+    if (p) { p->lds_gate = (int)o; p->max_ngate = max_ngate; }
+    o = up(o + (size_t)2 * TILE_M * max_ngate * 4);
+    return o;
+}
+static bool tower_fused_ok(const Ctx& x) {
+    const aread_model* m = x.m;
+    const aread_model_cfg& c = m->cfg;
+    if (g_fused_mode < 0) {
+        const char* e = getenv("AREAD_FUSED_TOWERS");
+        g_fused_mode = e ? atoi(e) : 0;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&g_n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            g_n_cu = 0;
+    }
+    if (!g_fused_mode || c.precision != 1 || m->is_mlp) return false;
+    if (x.n_tiles > g_n_cu) return false;                    // every workgroup of a segment must be resident (one per CU)
+    if (m->n_heads > MAX_TOWER || m->ld_h > 64) return false;
+    int prev_w = m->experts.L[m->experts.n_layers - 1].out_dim;
+    for (int l = 0; l < c.n_level; ++l) {
+        const int n_src = l == 0 ? c.n_expert : c.n_tower[l - 1];
+        if (c.n_tower[l] > MAX_TOWER || n_src > MAX_TOWER) return false;
+        for (int j = 0; j < m->towers[l].n_layers; ++j) {
+            const LayerL& L = m->towers[l].L[j];
+            if (L.in_dim != prev_w || L.in_dim % 8 || L.out_dim % 4 || L.out_dim > 64 || L.ncols > 256) return false;
+            if (L.G * ((L.out_dim + 15) / 16) > 4 * TF_MAX_UNITS) return false;
+            prev_w = L.out_dim;
+        }
+    }
+    if (prev_w != m->h_last) return false;
+    return tower_fwd_lds(m, nullptr) + 4096 <= 160 * 1024;
+}
+
+static int tower_fused_fwd(Ctx& x, bool want_gates) {
+    const aread_model* m = x.m;
+    const aread_call* c = x.c;
+    const aread_model_cfg& cfg = m->cfg;
+    float* ws = x.ws;
+    const float* P = x.params;
+    TFwdP p = {};
+    p.n_level = cfg.n_level; p.n_layers = m->towers[0].n_layers; p.train = c->train; p.mode = c->mode;
+    p.seed = c->drop_seed; p.thr = x.thr; p.keep_scale = x.keep_scale;
+    for (int l = 0; l < cfg.n_level; ++l) {
+        p.n_t[l] = cfg.n_tower[l]; p.mask_off[l] = m->mask_off[l]; p.gate_off[l] = m->gate_off[l];
+        p.In[l] = ws + x.w.In[l];
+        for (int j = 0; j < m->towers[l].n_layers; ++j) {
+            const LayerL& L = m->towers[l].L[j];
+            const LayerWs& lw = x.w.tw[l][j];
+            TFLayer& T = p.L[l][j];
+            T.n_t = L.G; T.in_w = L.in_dim; T.out_w = L.out_dim; T.ncols = L.ncols;
+            T.ks = (L.in_dim + 31) / 32; T.nfr = (L.out_dim + 15) / 16; T.pk = L.in_dim >= 32 ? 4 : L.in_dim / 8;
+            T.stack = L.stack; T.layer = L.layer;
+            T.wimg = (const __bf16*)(ws + lw.wimg_f);
+            T.bias = P + L.b; T.gamma = P + L.gamma; T.beta = P + L.beta;
+            T.rmean = c->stats + L.rmean; T.rvar = c->stats + L.rvar;
+            T.H = ws + lw.H; T.Act = ws + lw.Act; T.part = ws + lw.part; T.mean = ws + lw.mean; T.rstd = ws + lw.rstd; T.var = ws + lw.var;
+        }
+    }
+    const int nle = m->experts.n_layers;
+    p.X = ws + x.w.ex[nle - 1].Act; p.n_exp = cfg.n_expert; p.xw = m->experts.L[nle - 1].out_dim;
+    p.glogE = ws + x.w.glogE; p.ld_ge = m->ld_ge; p.glogT = ws + x.w.glogT; p.ld_gt = m->ld_gt;
+    p.gate_part = want_gates ? ws + x.w.gate_part : nullptr;
+    p.hc = ws + x.w.hc; p.lin = ws + x.w.lin; p.head_w = P + m->head_w; p.head_ld = m->head_ld; p.D = m->D; p.n_heads = m->n_heads;
+    p.ld_h = m->ld_h; p.h_last = m->h_last;
+    p.z = ws + x.w.z; p.prob = ws + x.w.prob; p.dz = ws + x.w.dz; p.probs_out = c->probs; p.B = c->B;
+    p.y = c->y; p.seg_weight = c->seg_weight; p.loss_part = (c->y && c->loss_out) ? ws + x.w.loss_part : nullptr;
+    p.cnt = (unsigned*)(ws + x.w.tf_sync); p.err = p.cnt + AREAD_MAX_LEVEL * AREAD_MAX_LAYER * MAX_SEG;
+    p.stamps = g_tf_stamps ? (unsigned long long*)(ws + x.w.misc_part) : nullptr;   // diagnostics: misc_part is free during the forward
+    p.r = x.r; p.mp = x.mp;
+    const size_t lds = tower_fwd_lds(m, &p);
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        AR_HIP(hipFuncSetAttribute((const void*)k_tower_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set = lds;
+    }
+    AR_HIP(hipMemsetAsync(p.cnt, 0, (size_t)(AREAD_MAX_LEVEL * AREAD_MAX_LAYER * MAX_SEG + 16) * sizeof(unsigned), x.st));
+    hipLaunchKernelGGL(k_tower_fwd, dim3(x.n_tiles), dim3(TF_THREADS), lds, x.st, p);
+    AR_LAUNCH_CHECK();
+    return AREAD_OK;
+}
+
 extern "C" int aread_forward(const aread_model* m, const aread_call* c, const float* e_in, void* stream) {
     Ctx x;
     TRY(make_ctx(m, c, stream, &x));
@@ -215,7 +352,8 @@ extern "C" int aread_forward(const aread_model* m, const aread_call* c, const fl
     mp.group_emb = P + m->group_emb;
     mp.active = (uint8_t*)(ws + x.w.active); mp.kact = (int32_t*)(ws + x.w.kact); mp.n0act = mp.kact + MAX_SEG;
     mp.seg_dom = (int32_t*)(ws + x.w.seg_dom); mp.grp = ws + x.w.grp;
-    if (cfg.precision == 1) TRY(prepare_wimg(x, 0));        // forward weight images: the first expert GEMM needs them
+    const bool fused_towers = tower_fused_ok(x);
+    if (cfg.precision == 1 && (fused_towers || wide_any())) TRY(prepare_wimg(x, 0));   // forward weight images (wide GEMM, fused towers)
     // 1.-3. (side stream, joined before the MMoE mix: the expert layers need none of it) mask tables, row-wise trunk,
     // gate logits, cross-network part of the heads
     TRY(fork_side(x));
@@ -224,7 +362,7 @@ extern "C" int aread_forward(const aread_model* m, const aread_call* c, const fl
         x.st = x.side;
         LAUNCH(k_mask_prep, dim3(1), dim3(256), mp);
         if (c->probs) AR_HIP(hipMemsetAsync(c->probs, 0, (size_t)m->n_heads * c->B * sizeof(float), x.st));
-        if (c->train && cfg.precision == 1) { TRY(transpose_weights(x)); TRY(prepare_wimg(x, 1)); }
+        if (c->train && cfg.precision == 1) { TRY(transpose_weights(x)); if (wide_any()) TRY(prepare_wimg(x, 1)); }
         RowwiseP rw = {};
         rw.e = e_in; rw.cn = ws + x.w.cn; rw.lin = ws + x.w.lin; rw.xw = ws + x.w.xw; rw.q = ws + x.w.q; rw.grp = ws + x.w.grp;
         rw.lin_w = P + m->lin_w; rw.lin_b = P + m->lin_b; rw.cn_w = P + m->cn_w; rw.cn_b = P + m->cn_b;
@@ -240,17 +378,24 @@ extern "C" int aread_forward(const aread_model* m, const aread_call* c, const fl
                         m->n_heads, D, 0, 1));
         x.st = main_st;
     }
+    phase_mark(x.st, 0);
     // 4. experts
     TRY(stack_fwd(x, m->experts, x.w.ex, e_in, -1));
-    // 5. MMoE mix -> level-0 tower inputs
+    phase_mark(x.st, 1);
+    // 5.-7. MMoE mix, tower pyramid, heads + fused bagging loss: one launch when the configuration allows it
     TRY(join_side(x));
+    const bool want_gates = c->gate_stats != nullptr && m->gate_rows > 0;
+    const bool have_loss = c->y && c->loss_out;
+    if (fused_towers) {
+        TRY(tower_fused_fwd(x, want_gates));
+        if (want_gates) LAUNCH(k_gate_stats, dim3(c->n_seg), dim3(256), ws + x.w.gate_part, m->ld_gt, m->gate_rows, c->gate_stats, x.r);
+    } else {
     const LayerL& EL = m->experts.L[m->experts.n_layers - 1];
     Mix0P m0 = {};
     m0.glog = ws + x.w.glogE; m0.ld_g = m->ld_ge; m0.X = ws + x.w.ex[m->experts.n_layers - 1].Act; m0.In0 = ws + x.w.In[0];
     m0.n_t = cfg.n_tower[0]; m0.n_exp = cfg.n_expert; m0.h = EL.out_dim; m0.r = x.r; m0.mp = x.mp;
     LAUNCH(k_mix0, dim3(cdiv(x.rows * m0.n_t * (m0.h / 4), 256)), dim3(256), m0);
     // 6. tower pyramid
-    const bool want_gates = c->gate_stats != nullptr && m->gate_rows > 0;
     for (int l = 0; l < cfg.n_level; ++l) {
         const StackL& S = m->towers[l];
         if (l > 0) {
@@ -274,6 +419,10 @@ extern "C" int aread_forward(const aread_model* m, const aread_call* c, const fl
     hp.y = c->y; hp.seg_weight = c->seg_weight; hp.dprobs = nullptr;
     hp.loss_part = (c->y && c->loss_out) ? ws + x.w.loss_part : nullptr; hp.level = LL; hp.r = x.r; hp.mp = x.mp;
     LAUNCH(k_heads_fwd, dim3(x.n_tiles * SUB), dim3(256), hp);
+    }
+    phase_mark(x.st, 2);
+    HeadsP hp = {};
+    hp.loss_part = have_loss ? ws + x.w.loss_part : nullptr;
     const bool side_tail = hp.loss_part || (c->train && c->update_running);
     if (side_tail) TRY(fork_side(x));
     if (hp.loss_part) {
@@ -322,15 +471,23 @@ static int wgrad(Ctx& x, const float* dY, int64_t ld_dy, int64_t dy_gs, const fl
     g.M = Mg; g.N = Ng; g.K = (int)x.rows; g.G = G;
     g.k_split = ks.k_split; g.k_chunk = ks.k_chunk;
     g.gate_axis = 2; g.tile_seg = x.r.tile_seg; g.tile_valid = x.r.tile_valid; g.active = active; g.active_ld = MAX_TOWER;
-    TRY(fork_side(x));                                   // everything this wgrad reads has been issued on the main stream
-    // split-bf16 mode: the row-contiguous operands go through the transposing LDS reads (k_gemm_bf3_rc), 3 bf16 MFMA
-    // products instead of the fp32 MFMA -- 1.8x faster on the expert-L1 shape
-    if (x.m->cfg.precision == 1) TRY(launch_gemm_bf3_rc(g, x.side));
-    else TRY(launch_gemm(g, false, false, x.side));
-    AR_CHECK_ARG(x.splitk.n < MAX_WGRADS, "too many wgrads");
+    AR_CHECK_ARG(x.splitk.n < MAX_WGRADS && x.n_pend < MAX_WGRADS, "too many wgrads");
+    x.pend[x.n_pend++] = g;                              // launched by the next flush_wgrads (its operands stay in the workspace)
     SplitKOne& d = x.splitk.d[x.splitk.n++];
     d.slab = x.ws + slab_off; d.out = out; d.k_split = ks.k_split; d.G = G; d.M = Mg; d.N = Ng; d.ldo = ldo; d.o_gs = o_gs;
     d.transposed = swap ? 1 : 0;
+    return AREAD_OK;
+}
+
+// fork once, then every pending weight-gradient GEMM on the side stream.  split-bf16 mode: the row-contiguous operands go
+// through the transposing LDS reads (k_gemm_bf3_rc), 3 bf16 MFMA products instead of the fp32 MFMA.
+static int flush_wgrads(Ctx& x, bool fork) {
+    if (fork) TRY(fork_side(x));
+    for (int i = 0; i < x.n_pend; ++i) {
+        if (x.m->cfg.precision == 1) TRY(launch_gemm_bf3_rc(x.pend[i], x.side));
+        else TRY(launch_gemm(x.pend[i], false, false, x.side));
+    }
+    x.n_pend = 0;
     return AREAD_OK;
 }
 
@@ -341,8 +498,8 @@ static int flush_reductions(Ctx& x) {
             const int64_t e = (int64_t)x.splitk.d[i].G * x.splitk.d[i].M * x.splitk.d[i].N;
             if (e > mx) mx = e;
         }
-        int bx = cdiv(mx, 64);
-        if (bx > 2048) bx = 2048;
+        int bx = cdiv(mx, 128);
+        if (bx > 2304) bx = 2304;
         LAUNCH(k_splitk_reduce_all, dim3(bx, x.splitk.n), dim3(256), x.splitk);
         x.splitk.n = 0;
     }
@@ -427,6 +584,7 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     const int D = m->D, E = m->E, LL = cfg.n_level - 1;
     float* ws = x.ws;
     const float* P = x.params;
+    phase_mark(x.st, 3);
     AR_HIP(hipMemsetAsync(grads, 0, (size_t)m->n_params * sizeof(float), x.st));
     // 1. dz
     HeadsP hp = {};
@@ -441,15 +599,12 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     hb.part = ws + x.w.misc_part; hb.ldp = 1024; hb.r = x.r;
     AR_CHECK_ARG(m->n_heads * m->h_last <= 1024, "aread_backward: n_heads*h_last too large");
     LAUNCH(k_heads_bwd, dim3(x.n_tiles * SUB), dim3(256), hb);
-    TRY(fork_side(x));
-    hipLaunchKernelGGL(k_reduce_tiles, dim3(cdiv(m->n_heads * m->h_last, 32)), dim3(256), 0, x.side, ws + x.w.misc_part,
-                       (int64_t)1024, m->n_heads * m->h_last, grads + m->head_w + D, m->h_last, (int64_t)m->head_ld, 0, SUB, x.r);
-    AR_LAUNCH_CHECK();
-    // dcn = dz V[:, :D]   and   dV[:, :D] = dz^T cn
+    // dcn = dz V[:, :D]   and (queued for the side stream)   dV[:, :D] = dz^T cn
     TRY(simple_gemm(x, ws + x.w.dz, m->ld_h, true, P + m->head_w, m->head_ld, false, ws + x.w.dcn, D, nullptr, (int)x.rows, D,
                     m->n_heads, 0, 1));
     TRY(wgrad(x, ws + x.w.dz, m->ld_h, 0, ws + x.w.cn, D, 0, 1, m->n_heads, D, grads + m->head_w, m->head_ld, 0, nullptr, x.w.slab_head));
-    // 3. tower pyramid, top down
+    phase_mark(x.st, 4);
+    // 3. tower pyramid, top down (the weight gradients queue up)
     for (int l = LL; l >= 0; --l) {
         const StackL& S = m->towers[l];
         for (int j = S.n_layers - 1; j >= 0; --j) {
@@ -468,17 +623,8 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
             LAUNCH(k_mixl_bwd, dim3(x.n_tiles * SUB), dim3(256), mb);
         }
     }
-    // tower-gate input gradient dq = dglogT Tw: ready now, only needed by the row-wise backward -> side stream
-    const hipStream_t main_st0 = x.st;
-    if (m->gate_rows > 0) {
-        TRY(fork_side(x));
-        x.st = x.side;
-        TRY(simple_gemm(x, ws + x.w.dglogT, m->ld_gt, true, P + m->tgate_w, 2 * E, false, ws + x.w.dq, 2 * E, nullptr, (int)x.rows,
-                        2 * E, m->gate_rows, 0, 1));
-        x.st = main_st0;
-    } else {
-        AR_HIP(hipMemsetAsync(ws + x.w.dq, 0, (size_t)x.rows * 2 * E * sizeof(float), x.st));
-    }
+    phase_mark(x.st, 5);
+    if (m->gate_rows == 0) AR_HIP(hipMemsetAsync(ws + x.w.dq, 0, (size_t)x.rows * 2 * E * sizeof(float), x.st));
     // 4. MMoE mix backward
     const int nle = m->experts.n_layers;
     const LayerL& EL = m->experts.L[nle - 1];
@@ -487,27 +633,27 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     m0.dU = ws + x.w.dIn[0]; m0.dX = ws + x.w.ex[nle - 1].dAct; m0.n_t = cfg.n_tower[0]; m0.n_exp = cfg.n_expert; m0.h = EL.out_dim;
     m0.r = x.r; m0.mp = x.mp;
     LAUNCH(k_mix0_bwd, dim3(x.n_tiles * SUB), dim3(256), m0);
-    // MMoE-gate part of dE (deg = dglogE Gw) on the side stream; the row-wise backward adds it
-    {
-        TRY(fork_side(x));
-        x.st = x.side;
-        TRY(simple_gemm(x, ws + x.w.dglogE, m->ld_ge, true, P + m->gate_w, D, false, ws + x.w.deg, D, nullptr, (int)x.rows, D,
-                        cfg.n_tower[0] * cfg.n_expert, 0, 1));
-        x.st = main_st0;
-    }
-    // the row-wise backward only needs the side stream up to here (dq, deg), not the weight-gradient GEMMs behind it
-    hipEvent_t ev_gates = x.m->ev[x.ev_next++ % (x.m->n_ev - 1)];
-    AR_HIP(hipEventRecord(ev_gates, x.side));
-    // 4b. gate weight / bias gradients (side stream): they only need dglogE / dglogT, so they are queued BEFORE the
-    // big expert weight gradients instead of lengthening the side stream's tail after them
+    // ---- side batch A (ONE fork): everything off the critical path that the tower / gate backward has made ready -------------
     const int n_ge = cfg.n_tower[0] * cfg.n_expert;
     const hipStream_t main_st = x.st;
+    AR_CHECK_ARG(m->gate_rows <= 1024 && n_ge <= 1024, "aread_backward: too many gate rows");
     TRY(wgrad(x, ws + x.w.dglogE, m->ld_ge, 0, e_in, D, 0, 1, n_ge, D, grads + m->gate_w, D, 0, nullptr, x.w.slab_gate));
     if (m->gate_rows > 0)
         TRY(wgrad(x, ws + x.w.dglogT, m->ld_gt, 0, ws + x.w.q, 2 * E, 0, 1, m->gate_rows, 2 * E, grads + m->tgate_w, 2 * E, 0, nullptr,
                   x.w.slab_tgate));
-    AR_CHECK_ARG(m->gate_rows <= 1024 && n_ge <= 1024, "aread_backward: too many gate rows");
-    x.st = x.side;                                       // (already forked by wgrad)
+    TRY(fork_side(x));
+    x.st = x.side;
+    // gate-input gradients first: dq = dglogT Tw (tower gates) and deg = dglogE Gw (MMoE gates) feed the row-wise backward
+    if (m->gate_rows > 0)
+        TRY(simple_gemm(x, ws + x.w.dglogT, m->ld_gt, true, P + m->tgate_w, 2 * E, false, ws + x.w.dq, 2 * E, nullptr, (int)x.rows,
+                        2 * E, m->gate_rows, 0, 1));
+    TRY(simple_gemm(x, ws + x.w.dglogE, m->ld_ge, true, P + m->gate_w, D, false, ws + x.w.deg, D, nullptr, (int)x.rows, D,
+                    n_ge, 0, 1));
+    hipEvent_t ev_gates = x.m->ev[x.ev_next++ % (x.m->n_ev - 1)];
+    AR_HIP(hipEventRecord(ev_gates, x.side));
+    // head tails (partials of k_heads_bwd), gate biases: all through misc_part, in this order on this one stream
+    LAUNCH(k_reduce_tiles, dim3(cdiv(m->n_heads * m->h_last, 32)), dim3(256), ws + x.w.misc_part, (int64_t)1024, m->n_heads * m->h_last,
+           grads + m->head_w + D, m->h_last, (int64_t)m->head_ld, 0, SUB, x.r);
     LAUNCH(k_colsum, dim3(x.n_tiles), dim3(256), ws + x.w.dglogE, (int64_t)m->ld_ge, n_ge, ws + x.w.misc_part, (int64_t)1024, x.r);
     LAUNCH(k_reduce_tiles, dim3(cdiv(n_ge, 32)), dim3(256), ws + x.w.misc_part, (int64_t)1024, n_ge, grads + m->gate_b, n_ge,
            (int64_t)0, 0, 1, x.r);
@@ -518,32 +664,25 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
                grads + m->tgate_b, m->gate_rows, (int64_t)0, 0, 1, x.r);
     }
     x.st = main_st;
-    // 5. experts; the first layer writes de_out
-    for (int j = nle - 1; j >= 0; --j) {
-        const float* in = j == 0 ? e_in : ws + x.w.ex[j - 1].Act;
-        float* d_in = j == 0 ? de_out : ws + x.w.ex[j - 1].dAct;
-        TRY(layer_bwd(x, m->experts.L[j], x.w.ex[j], in, d_in, 0, grads, -1, x.w.slab_ex[j]));
-    }
-    // every weight-gradient GEMM and bias partial is queued: their batched reductions follow on the side stream
-    // now, concurrently with the row-wise backward on the main stream (they do not depend on it)
-    TRY(fork_side(x));
-    x.st = x.side;
-    TRY(flush_reductions(x));
-    x.st = main_st;
-    // 7. row-wise trunk backward (adds into de_out): the end of the critical path; needs dq and deg from the side stream
-    AR_HIP(hipStreamWaitEvent(x.st, ev_gates, 0));
-    RowwiseBwdP rb = {};
-    rb.e = e_in; rb.xw = ws + x.w.xw; rb.dcn = ws + x.w.dcn; rb.dlin = ws + x.w.dlin; rb.dq = ws + x.w.dq; rb.deg = ws + x.w.deg;
-    rb.lin_w = P + m->lin_w; rb.cn_w = P + m->cn_w; rb.cn_b = P + m->cn_b;
-    rb.de = de_out; rb.part = ws + x.w.rw_part; rb.part_ld = (int64_t)(cfg.n_cross + 2) * D + 8; rb.dgrp_part = ws + x.w.dgrp_part;
-    rb.D = D; rb.E = E; rb.n_cross = cfg.n_cross; rb.dom_field = cfg.domain_field; rb.rows = x.rows; rb.r = x.r;
-    AR_CHECK_ARG(D <= 1024 && cfg.n_cross <= MAX_CROSS, "aread_backward: D=%d > 1024 or too many cross layers", D);
-    if (D <= 384) launch_rowwise_bwd<3>(x, rb); else if (D <= 768) launch_rowwise_bwd<6>(x, rb); else launch_rowwise_bwd<8>(x, rb);
-    AR_LAUNCH_CHECK();
-    // 8. everything that only finishes parameter gradients runs on the side stream
-    TRY(fork_side(x));
-    x.st = x.side;
+    TRY(flush_wgrads(x, false));                         // head, tower and gate weight gradients (the fork above covers them)
+    // 4a. row-wise trunk backward on the second side stream, beside the expert backward: it needs dcn / dlin (main stream,
+    // before the fork) and dq / deg (side stream) and WRITES de_out; the expert-L1 dgrad accumulates onto it later.
+    // (No stream ever waits on its own event and no two forked streams wait on each other: hipStreamEndCapture walks the
+    // fork relation recursively and does not terminate on such a cycle.)
+    hipEvent_t ev_rw = x.m->ev[x.ev_next++ % (x.m->n_ev - 1)];
+    const hipStream_t rw_stream = m->side2;
     {
+        AR_HIP(hipStreamWaitEvent(rw_stream, ev_gates, 0));
+        x.st = rw_stream;
+        RowwiseBwdP rb = {};
+        rb.e = e_in; rb.xw = ws + x.w.xw; rb.dcn = ws + x.w.dcn; rb.dlin = ws + x.w.dlin; rb.dq = ws + x.w.dq; rb.deg = ws + x.w.deg;
+        rb.lin_w = P + m->lin_w; rb.cn_w = P + m->cn_w; rb.cn_b = P + m->cn_b;
+        rb.de = de_out; rb.part = ws + x.w.rw_part; rb.part_ld = (int64_t)(cfg.n_cross + 2) * D + 8; rb.dgrp_part = ws + x.w.dgrp_part;
+        rb.D = D; rb.E = E; rb.n_cross = cfg.n_cross; rb.dom_field = cfg.domain_field; rb.rows = x.rows; rb.de_init = 1; rb.r = x.r;
+        AR_CHECK_ARG(D <= 1024 && cfg.n_cross <= MAX_CROSS, "aread_backward: D=%d > 1024 or too many cross layers", D);
+        if (D <= 384) launch_rowwise_bwd<3>(x, rb); else if (D <= 768) launch_rowwise_bwd<6>(x, rb); else launch_rowwise_bwd<8>(x, rb);
+        AR_LAUNCH_CHECK();
+        AR_HIP(hipEventRecord(ev_rw, rw_stream));
         RowwiseFinP rf = {};
         rf.part = ws + x.w.rw_part; rf.ld = rb.part_ld; rf.cn_w = P + m->cn_w; rf.cn_b = P + m->cn_b;
         rf.g_cn_w = grads + m->cn_w; rf.g_cn_b = grads + m->cn_b; rf.g_lin_w = grads + m->lin_w; rf.g_lin_b = grads + m->lin_b;
@@ -555,13 +694,54 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
             case 3: LAUNCH(k_rowwise_finish<3>, dim3(cdiv(D, 8)), dim3(256), rf); break;
             default: LAUNCH(k_rowwise_finish<4>, dim3(cdiv(D, 8)), dim3(256), rf); break;
         }
+        LAUNCH(k_seg_reduce, dim3(c->n_seg, cdiv(E, 16)), dim3(256), ws + x.w.dgrp_part, (int64_t)E, E, ws + x.w.grp, RWB_SUB, x.r);
+        LAUNCH(k_grp_bwd, dim3(1), dim3(256), ws + x.w.grp, grads + m->group_emb, cfg.n_tower[0], E, x.r, x.mp);
+        x.st = main_st;
     }
-    LAUNCH(k_seg_reduce, dim3(c->n_seg, cdiv(E, 16)), dim3(256), ws + x.w.dgrp_part, (int64_t)E, E, ws + x.w.grp, RWB_SUB, x.r);
-    LAUNCH(k_grp_bwd, dim3(1), dim3(256), ws + x.w.grp, grads + m->group_emb, cfg.n_tower[0], E, x.r, x.mp);
+    phase_mark(x.st, 6);
+    // 5. experts; the first layer ADDS its input gradient onto de_out, which the row-wise backward (side2) has initialised
+    for (int j = nle - 1; j >= 0; --j) {
+        const float* in = j == 0 ? e_in : ws + x.w.ex[j - 1].Act;
+        float* d_in = j == 0 ? de_out : ws + x.w.ex[j - 1].dAct;
+        if (j == 0) {
+            // ---- side batch B (one fork): the deeper expert layers' weight gradients, then the split-K / bias reductions of
+            // everything queued so far, beside the first layer's backward: only that layer's reduction is left for the tail
+            TRY(flush_wgrads(x, true));
+            x.st = x.side;
+            TRY(flush_reductions(x));
+            x.st = main_st;
+            AR_HIP(hipStreamWaitEvent(x.st, ev_rw, 0));
+        }
+        TRY(layer_bwd(x, m->experts.L[j], x.w.ex[j], in, d_in, j == 0 ? 1 : 0, grads, -1, x.w.slab_ex[j]));
+    }
+    phase_mark(x.st, 7);
+    // ---- side batch C (one fork): the first expert layer's weight gradient and its reductions
+    TRY(flush_wgrads(x, true));
+    x.st = x.side;
+    TRY(flush_reductions(x));
     x.st = main_st;
+    {   // the second side stream (row-wise parameter gradients, finished long ago) joins the main stream
+        hipEvent_t e2 = x.m->ev[x.ev_next++ % (x.m->n_ev - 1)];
+        AR_HIP(hipEventRecord(e2, rw_stream));
+        AR_HIP(hipStreamWaitEvent(main_st, e2, 0));
+    }
     // de_out is complete on the main stream here; the parameter gradients complete on the side stream.
     // async_tail: the caller overlaps its own work (embedding scatter) and calls aread_join() afterwards.
     if (!(c->async_tail & 1)) TRY(join_side(x));
+    return AREAD_OK;
+}
+
+extern "C" int aread_debug_set(const char* key, int value) {
+    AR_CHECK_ARG(key != nullptr, "aread_debug_set: null key");
+    if (!strcmp(key, "fused_towers")) g_fused_mode = value;
+    else if (!strcmp(key, "wide_gemm")) g_wide_mode = value;
+    else if (!strcmp(key, "tf_stamps")) g_tf_stamps = value;
+    else if (!strcmp(key, "phase_events")) g_phase_on = value;
+    else AR_CHECK_ARG(false, "aread_debug_set: unknown key %s", key);
+    if (g_n_cu == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&g_n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) g_n_cu = 0;
+    }
     return AREAD_OK;
 }
 
@@ -611,7 +791,7 @@ static int make_mlp_ctx(const aread_model* m, const aread_mlp_call* c, void* str
     x->thr = drop ? drop_threshold(m->cfg.dropout) : 0u;
     x->keep_scale = drop ? 1.0f / (1.0f - m->cfg.dropout) : 1.f;
     x->params = c->params;
-    x->splitk.n = 0; x->bias.n = 0;
+    x->splitk.n = 0; x->bias.n = 0; x->n_pend = 0;
     TRY0(model_streams_init(m));
     x->side = m->side; x->ev_next = 0;
     return AREAD_OK;
@@ -625,8 +805,8 @@ extern "C" int aread_mlp_forward(const aread_model* m, const aread_mlp_call* c, 
     float* ws = x.ws;
     const int in = m->mlp_in, nl = m->experts.n_layers, last = m->h_last;
     LAUNCH(k_pad_rows, dim3(cdiv(x.rows * in, 256)), dim3(256), xin, (int64_t)in, ws + x.w.In[0], (int64_t)in, in, c->B, x.rows);
-    if (m->cfg.precision == 1) TRY(prepare_wimg(x, 0));
-    if (c->train && m->cfg.precision == 1) { TRY(transpose_weights(x)); TRY(prepare_wimg(x, 1)); }   // for the dgrad of aread_mlp_backward
+    if (m->cfg.precision == 1 && wide_any()) TRY(prepare_wimg(x, 0));
+    if (c->train && m->cfg.precision == 1) { TRY(transpose_weights(x)); if (wide_any()) TRY(prepare_wimg(x, 1)); }   // for the dgrad of aread_mlp_backward
     TRY(stack_fwd(x, m->experts, x.w.ex, ws + x.w.In[0], -1));
     const float* act = ws + x.w.ex[nl - 1].Act;
     if (m->mlp_out_layer) {
@@ -677,7 +857,7 @@ extern "C" int aread_mlp_backward(const aread_model* m, const aread_mlp_call* c,
     }
     if (dx) LAUNCH(k_pad_rows, dim3(cdiv(c->B * in, 256)), dim3(256), ws + x.w.dIn[0], (int64_t)in, dx, (int64_t)in, in, c->B, c->B);
     const hipStream_t main_st = x.st;
-    TRY(fork_side(x));
+    TRY(flush_wgrads(x, true));
     x.st = x.side;
     TRY(flush_reductions(x));
     x.st = main_st;

@@ -126,26 +126,56 @@ struct SplitKOne { const float* slab; float* out; int k_split, G, M, N; int64_t 
 #define MAX_WGRADS 24
 struct SplitKAllP { int n; SplitKOne d[MAX_WGRADS]; };
 __global__ __launch_bounds__(256) void k_splitk_reduce_all(const SplitKAllP a) {
-    __shared__ float s_acc[4][64];
+    // block = 32 groups of 4 consecutive elements x 8 interleaved slab groups: a thread sums the slabs k = kg, kg+8, ... (four
+    // independent 16-byte loads in flight), the 8 partial sums are combined through LDS in a fixed order.  Small weight
+    // gradients are cut into many slabs (up to rows/64): the slab loop must not be one serial chain.
+    __shared__ float4 s_acc[8][32];
     const SplitKOne& p = a.d[blockIdx.y];
     const int64_t per = (int64_t)p.G * p.M * p.N;
-    const int el = threadIdx.x & 63, kg = threadIdx.x >> 6;
-    for (int64_t base = (int64_t)blockIdx.x * 64; base < per; base += (int64_t)gridDim.x * 64) {
-        const int64_t idx = base + el;
-        float s = 0.f;
-        if (idx < per) {
-#pragma unroll 4
-            for (int k = kg; k < p.k_split; k += 4) s += p.slab[(int64_t)k * per + idx];
+    const int el = threadIdx.x & 31, kg = threadIdx.x >> 5;
+    const bool vec = (per & 3) == 0 && (p.N & 3) == 0;
+    const int64_t n_items = vec ? (per >> 2) : per;            // items of 4 elements (vector path) or single elements
+    for (int64_t base = (int64_t)blockIdx.x * 32; base < n_items; base += (int64_t)gridDim.x * 32) {
+        const int64_t it = base + el;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (it < n_items) {
+            if (vec) {
+                const float4* src = (const float4*)p.slab + it;
+                const int64_t per4 = per >> 2;
+                int k = kg;
+                for (; k + 24 < p.k_split; k += 32) {
+                    float4 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = src[(int64_t)(k + 8 * u) * per4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+                }
+                for (; k < p.k_split; k += 8) { const float4 v = src[(int64_t)k * per4]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+            } else {
+                for (int k = kg; k < p.k_split; k += 8) acc.x += p.slab[(int64_t)k * per + it];
+            }
         }
-        s_acc[kg][el] = s;
+        s_acc[kg][el] = acc;
         __syncthreads();
-        if (kg == 0 && idx < per) {
-            const float tot = (s_acc[0][el] + s_acc[1][el]) + (s_acc[2][el] + s_acc[3][el]);
+        if (kg == 0 && it < n_items) {
+            float4 t = s_acc[0][el];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) { const float4 b = s_acc[q][el]; t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w; }
+            const int64_t idx = vec ? (it << 2) : it;
             const int g = (int)(idx / ((int64_t)p.M * p.N));
             const int rem = (int)(idx - (int64_t)g * p.M * p.N);
             const int m = rem / p.N, n = rem - m * p.N;
-            if (p.transposed) p.out[(int64_t)g * p.o_gs + (int64_t)n * p.ldo + m] = tot;   // slab holds the transposed product
-            else p.out[(int64_t)g * p.o_gs + (int64_t)m * p.ldo + n] = tot;
+            if (!vec) {
+                if (p.transposed) p.out[(int64_t)g * p.o_gs + (int64_t)n * p.ldo + m] = t.x;
+                else p.out[(int64_t)g * p.o_gs + (int64_t)m * p.ldo + n] = t.x;
+            } else if (p.transposed) {                         // the slab holds the transposed product
+                float* o = p.out + (int64_t)g * p.o_gs + (int64_t)n * p.ldo + m;
+                o[0] = t.x; o[p.ldo] = t.y; o[2 * p.ldo] = t.z; o[3 * p.ldo] = t.w;
+            } else {
+                float* o = p.out + (int64_t)g * p.o_gs + (int64_t)m * p.ldo + n;
+                if ((p.ldo & 3) == 0 && (p.o_gs & 3) == 0 && (((uintptr_t)p.out) & 15) == 0) *(float4*)o = t;
+                else { o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w; }
+            }
         }
         __syncthreads();
     }
@@ -159,21 +189,32 @@ struct BiasOne { const float* cpart; const float* bpart; float* db; float* dgamm
 struct BiasAllP { int n; BiasOne d[MAX_BN_LAYERS_DECL]; RowsP r; ModeP mp; };
 __global__ __launch_bounds__(256) void k_bias_reduce_all(const BiasAllP a) {
     __shared__ float s_acc[3][16][17];
+    __shared__ int s_seg[1024];                  // tile -> segment (or -1), with bit 30 set when the segment's BatchNorm applies
     const BiasOne& p = a.d[blockIdx.y];
     const int cl = threadIdx.x & 15, tg = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
     if (blockIdx.x * 16 >= p.ncols) return;
+    const int n_tiles = a.r.n_tiles < 1024 ? a.r.n_tiles : 1024;
+    for (int t = threadIdx.x; t < n_tiles; t += 256) {          // tile metadata once per block: the sums below then issue
+        const int sg = a.r.tile_seg[t];                         // nothing but independent loads
+        s_seg[t] = sg < 0 ? -1 : (sg | (a.r.seg_count[sg] > 1 ? (1 << 30) : 0));
+    }
+    __syncthreads();
     float sb = 0.f, s1 = 0.f, s2 = 0.f;
-    if (c < p.ncols)
+    if (c < p.ncols) {
+        const uint8_t* act = p.level >= 0 ? active_level(a.mp, p.level) : nullptr;
+        const int grp = c / p.h;
+#pragma unroll 4
         for (int t = tg; t < a.r.n_tiles; t += 16) {
-            const int sg = a.r.tile_seg[t];
-            if (sg < 0) continue;
+            const int v = t < 1024 ? s_seg[t] : (a.r.tile_seg[t] < 0 ? -1 : (a.r.tile_seg[t] | (a.r.seg_count[a.r.tile_seg[t]] > 1 ? (1 << 30) : 0)));
+            if (v < 0) continue;
             sb += p.cpart[(int64_t)t * p.ncols + c];
-            if (a.r.seg_count[sg] <= 1) continue;
-            if (p.level >= 0 && !active_level(a.mp, p.level)[sg * MAX_TOWER + c / p.h]) continue;
-            const float* bp = p.bpart + ((int64_t)t * p.ncols + c) * 2;
-            s1 += bp[0]; s2 += bp[1];
+            if (!(v >> 30)) continue;
+            if (act && !act[(v & 0xFFFF) * MAX_TOWER + grp]) continue;
+            const float2 bp = *(const float2*)(p.bpart + ((int64_t)t * p.ncols + c) * 2);
+            s1 += bp.x; s2 += bp.y;
         }
+    }
     s_acc[0][tg][cl] = sb; s_acc[1][tg][cl] = s1; s_acc[2][tg][cl] = s2;
     __syncthreads();
     if (tg < 3 && c < p.ncols) {
@@ -544,13 +585,14 @@ __global__ __launch_bounds__(256) void k_mix0_bwd(const Mix0BwdP p) {
 // Half a wave (32 lanes) per row, lane hl owns float4 chunks hl, hl+32, ...; a workgroup covers RWB_ROWS rows.
 // part layout per workgroup: [NC][D] EU | [D] EL | [D] DC | NC x sum ds_i | sum dl
 // ------------------------------------------------------------------------------------------------
-#define RWB_ROWS 32
+#define RWB_ROWS 16                    // 2 rows per half-wave: more workgroups in flight beat fewer partial slots (measured)
 #define RWB_SUB (TILE_M / RWB_ROWS)
 struct RowwiseBwdP {
     const float* e; const float* xw; const float* dcn; const float* dlin; const float* dq; const float* deg;
     const float* lin_w; const float* cn_w; const float* cn_b;
     float* de; float* part; int64_t part_ld; float* dgrp_part;
     int D, E, n_cross, dom_field; int64_t rows;
+    int de_init;                        // 1: de is written (every row of a live tile, zeros on its padding rows), not added to
     RowsP r;
 };
 
@@ -577,7 +619,7 @@ __global__ __launch_bounds__(256) void k_rowwise_bwd(const RowwiseBwdP p) {
         for (int i = 0; i < NCA; ++i) eu[i][v] = zero;
     }
     const int dom_c0 = p.dom_field * p.E, dom_c1 = dom_c0 + p.E;
-    for (int rr = r_lo + hw; rr < r_lo + RWB_ROWS; rr += 8) {
+    for (int rr = r_lo + hw; rr < r_lo + RWB_ROWS; rr += 8) {   // (RWB_ROWS / 8 rows per half-wave)
         const bool live = rr < r_hi;                   // (the whole half-wave agrees; dead rows only keep the shuffles uniform)
         const int64_t row = (int64_t)tile * TILE_M + rr;
         float4 e[NV], dc[NV], dg[NV], o[NV];
@@ -592,7 +634,7 @@ __global__ __launch_bounds__(256) void k_rowwise_bwd(const RowwiseBwdP p) {
             e[v] = on ? e4[ch] : zero;
             dc[v] = on ? g4[ch] : zero;
             dg[v] = on ? q4[ch] : zero;
-            o[v] = on ? o4[ch] : zero;
+            o[v] = (on && !p.de_init) ? o4[ch] : zero;
         }
         float xw[NCA];
 #pragma unroll
@@ -650,6 +692,7 @@ __global__ __launch_bounds__(256) void k_rowwise_bwd(const RowwiseBwdP p) {
                     t.x += dqv.x; t.y += dqv.y; t.z += dqv.z; t.w += dqv.w;
                 }
                 if (live) o4[ch] = t;
+                else if (p.de_init) o4[ch] = zero;       // padding row of a live tile: the dgrad that accumulates onto de reads it
                 el[v].x += dl * e[v].x; el[v].y += dl * e[v].y; el[v].z += dl * e[v].z; el[v].w += dl * e[v].w;
                 dcs[v].x += dc[v].x; dcs[v].y += dc[v].y; dcs[v].z += dc[v].z; dcs[v].w += dc[v].w;
             }

@@ -169,12 +169,13 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint32_t* __restri
     hist[(int64_t)threadIdx.x * nb + blockIdx.x] = s_h[threadIdx.x];
 }
 
-// exclusive scan of `total` ints in place, one workgroup.  Thread t owns elements [t*per, (t+1)*per): up to RS_SCAN_REG of
-// them are read with independent loads into registers (a plain dependent loop would pay one memory latency per element)
+// exclusive scan of `total` ints in place, one workgroup of 1024 threads.  Thread t owns the contiguous elements
+// [t*per, (t+1)*per): up to RS_SCAN_REG of them are read with independent loads into registers (a dependent loop would pay
+// one memory latency per element); the 1024 thread sums are scanned with wave shuffles + one 16-entry LDS pass.
 #define RS_SCAN_REG 24
 __global__ __launch_bounds__(1024) void k_rs_scan(int32_t* __restrict__ h, int64_t total) {
-    __shared__ int s_sum[1024];
-    const int tid = threadIdx.x;
+    __shared__ int s_wave[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t per = (total + 1023) / 1024, i0 = (int64_t)tid * per;
     const int64_t i1 = i0 + per < total ? i0 + per : total;
     int sum = 0;
@@ -188,15 +189,18 @@ __global__ __launch_bounds__(1024) void k_rs_scan(int32_t* __restrict__ h, int64
     } else {
         for (int64_t i = i0; i < i1; ++i) sum += h[i];
     }
-    s_sum[tid] = sum;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        const int v = tid >= d ? s_sum[tid - d] : 0;
-        __syncthreads();
-        s_sum[tid] += v;
-        __syncthreads();
+    int incl = sum;                                        // inclusive scan inside the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d);
+        if (lane >= d) incl += v;
     }
-    int run = s_sum[tid] - sum;
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) base += w < wave ? s_wave[w] : 0;
+    int run = base + incl - sum;
     if (in_reg) {
 #pragma unroll
         for (int j = 0; j < RS_SCAN_REG; ++j) {

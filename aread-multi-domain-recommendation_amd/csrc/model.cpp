@@ -153,6 +153,7 @@ extern "C" int aread_model_create(const aread_model_cfg* c, aread_model** out) {
 int model_streams_init(const aread_model* m) {
     if (m->side) return AREAD_OK;
     AR_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+    AR_HIP(hipStreamCreateWithFlags(&m->side2, hipStreamNonBlocking));
     for (int i = 0; i < 64; ++i) AR_HIP(hipEventCreateWithFlags(&m->ev[i], hipEventDisableTiming));
     m->n_ev = 64;
     return AREAD_OK;
@@ -163,6 +164,7 @@ extern "C" void aread_model_destroy(aread_model* m) {
     if (m->side) {
         for (int i = 0; i < m->n_ev; ++i) (void)hipEventDestroy(m->ev[i]);
         (void)hipStreamDestroy(m->side);
+        if (m->side2) (void)hipStreamDestroy(m->side2);
     }
     delete m;
 }
@@ -280,6 +282,7 @@ void ws_layout(const aread_model* m, int64_t B, int n_seg, WsLayout* w) {
     w->slab_tgate = slab(1, m->gate_rows > 0 ? m->gate_rows : 1, 2 * E);
     w->rw_part = take(&o, tiles * 4 * ((int64_t)(2 * MAX_CROSS + 1) * D + 4));
     w->misc_part = take(&o, tiles * 4 * 1024);
+    w->tf_sync = take(&o, 2 * (AREAD_MAX_LEVEL * AREAD_MAX_LAYER * MAX_SEG + 64));
     w->total = o;
 }
 
@@ -307,6 +310,8 @@ extern "C" int64_t aread_debug_ws_offset(const aread_model* m, int64_t B, int n_
     ws_layout(m, B, n_seg, &w);
     int l, j;
     char f[16];
+    if (!strcmp(name, "misc_part")) return w.misc_part;
+    if (!strcmp(name, "tf_err")) return w.tf_sync + AREAD_MAX_LEVEL * AREAD_MAX_LAYER * MAX_SEG;
     if (!strcmp(name, "cn")) return w.cn;
     if (!strcmp(name, "lin")) return w.lin;
     if (!strcmp(name, "xw")) return w.xw;

@@ -54,6 +54,7 @@ struct aread_model {
     int mlp_in = 0, mlp_out_layer = 0;
     int64_t out_w = 0, out_b = 0;
     mutable hipStream_t side = nullptr;
+    mutable hipStream_t side2 = nullptr;     // second fork-join stream: the row-wise trunk backward beside the expert backward
     mutable hipEvent_t ev[64] = {};
     mutable int n_ev = 0;
 };
@@ -68,6 +69,7 @@ struct WsLayout {                            // float offsets into the workspace
     int64_t active;                          // bytes region (as float offset): [n_level][MAX_SEG][MAX_TOWER]
     int64_t kact, seg_dom;                   // ints: active heads per seg, domain of each seg
     int64_t loss_part, gate_part, rw_part, misc_part;
+    int64_t tf_sync;                         // fused tower kernels: arrival counters [MAX_LEVEL*MAX_LAYER][MAX_SEG] x 2 (fwd, bwd) + error words
     int64_t slab_ex[AREAD_MAX_LAYER], slab_tw[AREAD_MAX_LEVEL][AREAD_MAX_LAYER], slab_head, slab_gate, slab_tgate;
     int64_t total;                           // floats
 };

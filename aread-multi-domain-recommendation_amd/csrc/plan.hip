@@ -74,6 +74,7 @@ __global__ __launch_bounds__(1024) void k_plan_prefix(PlanGeom g, int32_t* __res
     const int per = (g.n_waves + 15) / 16;
     const int w0 = wave * per, w1 = min(g.n_waves, w0 + per);
     int sum = 0, bad = 0;
+#pragma unroll 8
     for (int w = w0; w < w1; ++w) sum += cnt[(int64_t)w * MAX_SEG + lane];
     for (int w = w0 + lane; w < w1; w += WAVE) bad += cnt[(int64_t)g.n_waves * MAX_SEG + w];
 #pragma unroll
@@ -95,28 +96,33 @@ __global__ __launch_bounds__(1024) void k_plan_prefix(PlanGeom g, int32_t* __res
             run += c;
         }
     }
-    if (tid == 0) {
-        int row = 0;
-        for (int s = 0; s < MAX_SEG; ++s) {
-            const int c = s_total[s];
-            seg_count[s] = c;
-            seg_start[s] = row;
-            const int nt = (c + TILE_M - 1) / TILE_M;
-            for (int t = 0; t < nt; ++t) {
-                const int ti = row / TILE_M + t;
-                tile_seg[ti] = s;
-                const int v = c - t * TILE_M;
-                tile_valid[ti] = v > TILE_M ? TILE_M : v;
-            }
-            row += nt * TILE_M;
+    if (tid < MAX_SEG) {                                       // wave 0: lane = segment; tile ranges by a wave scan of the tile counts
+        const int c = s_total[tid];
+        const int nt = (c + TILE_M - 1) / TILE_M;
+        int incl = nt;
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) {
+            const int v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
         }
-        int nbad = 0;
-        for (int j = 0; j < 16; ++j) nbad += s_bad[j];
-        plan[PLAN_B] = g.B;
-        plan[PLAN_NSEG] = g.n_seg;
-        plan[PLAN_ROWS] = row;
-        plan[PLAN_NTILES] = row / TILE_M;
-        plan[PLAN_NBAD] = nbad;
+        const int first = incl - nt;
+        seg_count[tid] = c;
+        seg_start[tid] = first * TILE_M;
+        for (int t = 0; t < nt; ++t) {
+            tile_seg[first + t] = tid;
+            const int v = c - t * TILE_M;
+            tile_valid[first + t] = v > TILE_M ? TILE_M : v;
+        }
+        const int total_tiles = __shfl(incl, WAVE - 1);
+        if (tid == 0) {
+            int nbad = 0;
+            for (int j = 0; j < 16; ++j) nbad += s_bad[j];
+            plan[PLAN_B] = g.B;
+            plan[PLAN_NSEG] = g.n_seg;
+            plan[PLAN_ROWS] = total_tiles * TILE_M;
+            plan[PLAN_NTILES] = total_tiles;
+            plan[PLAN_NBAD] = nbad;
+        }
     }
 }
 

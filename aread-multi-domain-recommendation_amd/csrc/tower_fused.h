@@ -1,0 +1,534 @@
+// tower_fused.h -- the whole HEI tower pyramid of the FORWARD pass in one launch (split-bf16 mode):
+//   MMoE mix (aread.py:152-153) -> per level { masked gate mix (aread.py:282-295), [Linear -> BatchNorm -> ReLU -> Dropout] x
+//   n_layers (layer.py:203-229) } -> heads + sigmoid + bagging BCE and its gradient (aread.py:304-310, run.py:672-677).
+// It replaces k_mix0, k_mixl, the tower GEMMs, k_bn_act and k_heads_fwd: 16 dependent launches of 5-20 us each for 7 % of
+// the step's FLOPs become one launch whose BatchNorm statistics points are segment-scoped hand-offs INSIDE the kernel.
+//
+// One workgroup (256 threads, 4 waves) owns one 64-row plan tile for every tower of every level; a tile lies inside one
+// segment (domain), so the edge mask and the "tower is active" predicate are workgroup-uniform.  Per layer:
+//   A image : the layer input of all towers as split-bf16 (hi, lo) tiles in LDS, per (tower, 32-wide k-step) one block in
+//             the layout of gemm.h::bf3_off (conflict-free ds_read_b128 fragments); K is zero-padded to 32
+//   weights : fragments straight from the pre-tiled images k_prep_wimg wrote for this step (L2-resident, 139 KB in all)
+//   MFMA    : v_mfma_f32_16x16x32_bf16 x3 (hi*hi + hi*lo + lo*hi), operands swapped (weights as the A input) so that a
+//             lane holds 4 consecutive columns of one row; a "unit" = (tower, 16-column fragment) x 64 rows, units are
+//             dealt round-robin to the 4 waves, so the column statistics of a unit never leave its wave
+//   stats   : (mean, M2) of the tile per column -> global partials with write-through (sc1) 8-byte stores, one agent-scope
+//             counter add per workgroup, relaxed sc1 poll until the segment's tiles have all arrived, then every
+//             workgroup of the segment merges the partials (Chan, tile order) -- MI355X guide, Guideline 16 / "Valid
+//             forms": all payload stores and loads are sc1, every storing wave drains vmcnt before the barrier that
+//             precedes the counter add; the spin is bounded and raises an error word instead of hanging
+//   apply   : normalise + ReLU + dropout in registers; H (pre-BN) and Act go to the workspace exactly where the backward
+//             pass expects them; Act also stays in LDS (fp32) for the next A image, the next level's mix, or the heads.
+// All workgroups of a segment must be resident together: the launcher only takes this path when the tile count fits the
+// CU count (one workgroup per CU, ~150 KB of LDS); otherwise the layer-by-layer path of dense.hip runs.
+#pragma once
+#include "dense_kernels.h"
+#include "gemm.h"
+
+#define TF_THREADS 256
+#define TF_MAX_UNITS 4                  // units per wave and layer (16 in all)
+#define TF_SPIN_LIMIT (1u << 22)
+#define TF_MAX_SEG_TILES 256           // tiles of one segment whose row counts are cached in LDS
+#define TF_MERGE_Q 8                   // partial loads in flight per (column, tile quarter): covers segments of <= 32 tiles
+
+struct TFLayer {
+    int n_t, in_w, out_w, ncols;        // towers of the level, per-tower input / output width, n_t*out_w
+    int ks, nfr, pk;                    // 32-wide k-steps, 16-wide column fragments per tower, stored 8-wide planes per k-step
+                                        // (pk = 4, or in_w/8 when in_w < 32: the A image keeps no all-zero planes)
+    int stack, layer;                   // dropout site ids
+    const __bf16* wimg;                 // forward weight image (gemm_wide.h), NF = 2: [n_t][ks][hi | lo][64*32]
+    const float* bias; const float* gamma; const float* beta;
+    const float* rmean; const float* rvar;
+    float* H; float* Act; float* part; float* mean; float* rstd; float* var;
+};
+
+struct TFwdP {
+    int n_level, n_layers, train, mode;
+    uint32_t seed, thr; float keep_scale;
+    TFLayer L[AREAD_MAX_LEVEL][AREAD_MAX_LAYER];
+    int n_t[AREAD_MAX_LEVEL], mask_off[AREAD_MAX_LEVEL], gate_off[AREAD_MAX_LEVEL];
+    const float* X; int n_exp, xw;                       // expert outputs [rows][n_exp*xw]
+    const float* glogE; int ld_ge; const float* glogT; int ld_gt;
+    float* In[AREAD_MAX_LEVEL];                          // level inputs [rows][n_t*in_w] (the backward reads them)
+    float* gate_part;                                    // nullable: [n_tiles*SUB][ld_gt]
+    const float* hc; const float* lin; const float* head_w; int head_ld, D, n_heads, ld_h, h_last;
+    float* z; float* prob; float* dz; float* probs_out; int64_t B;
+    const float* y; const float* seg_weight; float* loss_part;
+    unsigned* cnt;                                       // [n_level*n_layers][MAX_SEG] arrival counters, zeroed per launch
+    unsigned* err;                                       // set to 1 when a bounded spin gives up
+    unsigned long long* stamps;                          // diagnostics only (nullable): [n_tiles][64] s_memrealtime at phase ends
+    int lds_aimg, lds_actf, lds_gate, max_ngate;         // byte offsets of the LDS regions; widest n_t*n_src
+    RowsP r; ModeP mp;
+};
+
+typedef unsigned long long tf_u64;
+__device__ __forceinline__ void tf_store_sc1(float* p, float a, float b) {
+    union { float f[2]; tf_u64 u; } v;
+    v.f[0] = a; v.f[1] = b;
+    __hip_atomic_store((tf_u64*)p, v.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void tf_load_sc1(const float* p, float& a, float& b) {
+    union { float f[2]; tf_u64 u; } v;
+    v.u = __hip_atomic_load((const tf_u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a = v.f[0]; b = v.f[1];
+}
+
+// (hi, lo) split of 8 consecutive floats into one 16-byte slot of each image
+__device__ __forceinline__ void tf_put8(__bf16* hi, __bf16* lo, int off, const float (&x)[8]) {
+    bf16x8 h, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        h[e] = (__bf16)x[e];
+        l[e] = (__bf16)(x[e] - (float)h[e]);
+    }
+    *(bf16x8*)(hi + off) = h;
+    *(bf16x8*)(lo + off) = l;
+}
+
+__global__ __launch_bounds__(TF_THREADS) void k_tower_fwd(const TFwdP p) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    __bf16* Aimg = (__bf16*)(smem + p.lds_aimg);          // [(tower, k-step)][hi | lo][64*32]
+    float* actf = (float*)(smem + p.lds_actf);            // [64][<= 256]: activations of the last finished layer, fp32
+    float* s_gate = (float*)(smem + p.lds_gate);          // [64][n_t*n_src] renormalised gates of a level transition
+    float* s_gam = s_gate + TILE_M * p.max_ngate;         // [64][n_t*n_src] masked, un-renormalised gates (statistics)
+    __shared__ float s_mean[256], s_rstd[256];
+    __shared__ float s_red[TF_THREADS];
+    __shared__ float s_cn[4][256], s_cm[4][256], s_cq[4][256];      // merge scratch: per tile quarter (count, mean, M2)
+    __shared__ float s_tv[TF_MAX_SEG_TILES];
+    __shared__ __attribute__((aligned(16))) __bf16 s_zero[8];
+    const __bf16* zslot = s_zero;
+    if (threadIdx.x < 8) s_zero[threadIdx.x] = (__bf16)0.f;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fk = lane >> 4;
+    const int tile = blockIdx.x;
+    const int seg = p.r.tile_seg[tile];
+    if (seg < 0) return;                                   // unused tile: takes part in no hand-off
+    const int nvalid = p.r.tile_valid[tile];
+    const int cnt = p.r.seg_count[seg];
+    const int t0 = p.r.seg_start[seg] / TILE_M, nt = (cnt + TILE_M - 1) / TILE_M;
+    const int64_t row0 = (int64_t)tile * TILE_M;
+    const bool bn = cnt > 1;
+    const uint8_t* masks = p.mp.masks ? p.mp.masks + (size_t)p.mp.seg_dom[seg] * p.mp.edge_count : nullptr;
+
+    // dropout keys of this lane's four rows (m = mi*16 + fr), rows-per-tile of the segment's tiles: read once
+    uint32_t dkey[4] = {0u, 0u, 0u, 0u};
+    if (p.train && p.thr) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int sm = p.r.row_sample[row0 + mi * 16 + fr];
+            dkey[mi] = drop_row_key(p.seed, (uint32_t)sm);
+        }
+    }
+    for (int t = tid; t < nt && t < TF_MAX_SEG_TILES; t += TF_THREADS) s_tv[t] = (float)p.r.tile_valid[t0 + t];
+
+    int n_stamp = 0;
+#define TF_STAMP()                                                                                       \
+    do {                                                                                                 \
+        if (p.stamps && tid == 0 && n_stamp < 64) p.stamps[(size_t)tile * 64 + n_stamp] = __builtin_amdgcn_s_memrealtime(); \
+        ++n_stamp;                                                                                       \
+    } while (0)
+    TF_STAMP();                                            // 0: start
+    int prev_cols = 0;                                     // width of actf (previous layer's n_t*out_w)
+    for (int l = 0; l < p.n_level; ++l) {
+        const TFLayer& L0 = p.L[l][0];
+        const int n_t = L0.n_t, in_w = L0.in_w, ks0 = L0.ks;
+        const uint8_t* act = active_level(p.mp, l) + seg * MAX_TOWER;
+        // ---------------- level input: gate mix of the previous level (or of the experts) -> In[l], A image ----------------
+        {
+            const int n_src = l == 0 ? p.n_exp : p.n_t[l - 1];
+            const int ngate = n_t * n_src;
+            // gates: one thread per (row, tower)
+            for (int it = tid; it < TILE_M * n_t; it += TF_THREADS) {
+                const int m = it / n_t, t = it - m * n_t;
+                const int64_t row = row0 + m;
+                const bool on = m < nvalid && act[t];
+                float a[MAX_TOWER], am[MAX_TOWER], ah[MAX_TOWER], S;
+                if (on) {
+                    if (l == 0) {                           // MMoE: plain softmax over the experts
+                        const float* gl = p.glogE + row * p.ld_ge + t * n_src;
+                        float mx = gl[0];
+                        for (int s = 1; s < n_src; ++s) mx = fmaxf(mx, gl[s]);
+                        float den = 0.f;
+                        for (int s = 0; s < n_src; ++s) den += __expf(gl[s] - mx);
+                        for (int s = 0; s < n_src; ++s) ah[s] = __expf(gl[s] - mx) / den;
+                    } else {
+                        gate_weights(p.glogT + row * p.ld_gt + p.gate_off[l] + t * n_src, n_src, masks ? masks + p.mask_off[l] : nullptr,
+                                     n_t, t, p.mp.mode, a, am, ah, &S);
+                    }
+                }
+                for (int s = 0; s < n_src; ++s) s_gate[m * ngate + t * n_src + s] = on ? ah[s] : 0.f;
+                if (l > 0 && p.gate_part)                   // un-renormalised masked gate: HEMP statistics (aread.py:290-295)
+                    for (int s = 0; s < n_src; ++s) s_gam[m * ngate + t * n_src + s] = on ? am[s] : 0.f;
+            }
+            __syncthreads();
+            TF_STAMP();                                      // gates
+            if (l > 0 && p.gate_part)
+                for (int gcol = tid; gcol < ngate; gcol += TF_THREADS) {
+                    float sum = 0.f;
+                    for (int m = 0; m < TILE_M; ++m) sum += s_gam[m * ngate + gcol];
+                    for (int q = 0; q < SUB; ++q) p.gate_part[((int64_t)tile * SUB + q) * p.ld_gt + p.gate_off[l] + gcol] = q == 0 ? sum : 0.f;
+                }
+            // weighted sums: one thread per (row, tower, 8 columns)
+            const int pk0 = L0.pk, bstride0 = 2 * pk0 * 512; // planes per k-step; elements per (tower, k-step) block [hi | lo]
+            const int g8 = in_w >> 3;                        // 8-column groups per tower (in_w % 8 == 0)
+            const int planes = ks0 * pk0;                    // 16-byte slots per tower row in the A image
+            for (int it = tid; it < TILE_M * n_t * planes; it += TF_THREADS) {
+                const int m = it / (n_t * planes), rem = it - m * (n_t * planes);
+                const int t = rem / planes, pl = rem - t * planes;
+                float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (pl < g8) {
+                    const float* gw = s_gate + m * ngate + t * n_src;
+                    if (l == 0) {
+                        const float* src = p.X + (row0 + m) * (int64_t)(n_src * p.xw) + pl * 8;
+                        for (int s = 0; s < n_src; ++s) {
+                            const float w = gw[s];
+                            if (w != 0.f) {
+                                const float4 x0 = *(const float4*)(src + s * p.xw), x1 = *(const float4*)(src + s * p.xw + 4);
+                                v[0] += w * x0.x; v[1] += w * x0.y; v[2] += w * x0.z; v[3] += w * x0.w;
+                                v[4] += w * x1.x; v[5] += w * x1.y; v[6] += w * x1.z; v[7] += w * x1.w;
+                            }
+                        }
+                    } else {
+                        const float* src = actf + m * prev_cols + pl * 8;
+                        for (int s = 0; s < n_src; ++s) {
+                            const float w = gw[s];
+                            if (w != 0.f) {
+                                const float4 x0 = *(const float4*)(src + s * in_w), x1 = *(const float4*)(src + s * in_w + 4);
+                                v[0] += w * x0.x; v[1] += w * x0.y; v[2] += w * x0.z; v[3] += w * x0.w;
+                                v[4] += w * x1.x; v[5] += w * x1.y; v[6] += w * x1.z; v[7] += w * x1.w;
+                            }
+                        }
+                    }
+                    float* dst = p.In[l] + (row0 + m) * (int64_t)(n_t * in_w) + t * in_w + pl * 8;
+                    *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+                    *(float4*)(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                }
+                const int blk = t * ks0 + pl / pk0;
+                tf_put8(Aimg + (size_t)blk * bstride0, Aimg + (size_t)blk * bstride0 + pk0 * 512, bf3_off(TILE_M, m, pl % pk0), v);
+            }
+            __syncthreads();
+            TF_STAMP();                                      // mix + A image
+        }
+        // ---------------- the level's layers -----------------------------------------------------------------------------
+        for (int j = 0; j < p.n_layers; ++j) {
+            const TFLayer& L = p.L[l][j];
+            const int ks = L.ks, nfr = L.nfr, out_w = L.out_w, ncols = L.ncols, pk = L.pk, bstride = 2 * pk * 512;
+            const int n_units = n_t * nfr;
+            f32x4 acc[TF_MAX_UNITS][4];
+            int ut[TF_MAX_UNITS], uf[TF_MAX_UNITS];
+            bool uon[TF_MAX_UNITS];
+#pragma unroll
+            for (int u = 0; u < TF_MAX_UNITS; ++u) {
+                const int unit = wave + 4 * u;
+                ut[u] = unit < n_units ? unit / nfr : 0;
+                uf[u] = unit < n_units ? unit - ut[u] * nfr : 0;
+                uon[u] = unit < n_units && act[ut[u]];
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) acc[u][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            if (ks <= 2) {
+                // all weight fragments of the layer in flight before the first MFMA (two L2 round trips otherwise serialise per unit)
+                bf16x8 wh[TF_MAX_UNITS][2], wl[TF_MAX_UNITS][2];
+#pragma unroll
+                for (int u = 0; u < TF_MAX_UNITS; ++u)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+                        if (uon[u] && s < ks) {
+                            const __bf16* wb = L.wimg + ((size_t)(ut[u] * ks + s)) * 4096 + bf3_off(64, uf[u] * 16 + fr, fk);
+                            wh[u][s] = *(const bf16x8*)wb; wl[u][s] = *(const bf16x8*)(wb + 2048);
+                        }
+#pragma unroll
+                for (int u = 0; u < TF_MAX_UNITS; ++u) {
+                    if (!uon[u]) continue;                   // wave-uniform
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        if (s >= ks) continue;
+                        const bool stored = fk < pk;         // planes >= pk of a narrow input are all zero and not stored
+                        const __bf16* ab = stored ? Aimg + ((size_t)(ut[u] * ks + s)) * bstride + bf3_off(TILE_M, fr, fk) : zslot;
+                        const int mstep = stored ? 128 : 0, lo_off = stored ? pk * 512 : 0;
+#pragma unroll
+                        for (int mi = 0; mi < 4; ++mi) {
+                            const bf16x8 ah = *(const bf16x8*)(ab + mi * mstep), al = *(const bf16x8*)(ab + lo_off + mi * mstep);
+                            acc[u][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[u][s], ah, acc[u][mi], 0, 0, 0);
+                            acc[u][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[u][s], al, acc[u][mi], 0, 0, 0);
+                            acc[u][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[u][s], ah, acc[u][mi], 0, 0, 0);
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < TF_MAX_UNITS; ++u) {
+                    if (!uon[u]) continue;                   // wave-uniform
+                    for (int s = 0; s < ks; ++s) {
+                        const __bf16* wb = L.wimg + ((size_t)(ut[u] * ks + s)) * 4096 + bf3_off(64, uf[u] * 16 + fr, fk);
+                        const bf16x8 wh = *(const bf16x8*)wb, wl = *(const bf16x8*)(wb + 2048);
+                        const bool stored = fk < pk;
+                        const __bf16* ab = stored ? Aimg + ((size_t)(ut[u] * ks + s)) * bstride + bf3_off(TILE_M, fr, fk) : zslot;
+                        const int mstep = stored ? 128 : 0, lo_off = stored ? pk * 512 : 0;
+#pragma unroll
+                        for (int mi = 0; mi < 4; ++mi) {
+                            const bf16x8 ah = *(const bf16x8*)(ab + mi * mstep), al = *(const bf16x8*)(ab + lo_off + mi * mstep);
+                            acc[u][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah, acc[u][mi], 0, 0, 0);
+                            acc[u][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, al, acc[u][mi], 0, 0, 0);
+                            acc[u][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah, acc[u][mi], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            TF_STAMP();                                      // MFMA
+            // ---- bias; per-column (mean, M2) of the tile -> partials; arrive; only then H -> workspace -----------------------
+            const bool sync_stats = p.train && bn;
+            float4 gam[TF_MAX_UNITS], bet[TF_MAX_UNITS];     // BatchNorm affine of this lane's columns: in flight across the hand-off
+#pragma unroll
+            for (int u = 0; u < TF_MAX_UNITS; ++u) {
+                gam[u] = make_float4(1.f, 1.f, 1.f, 1.f); bet[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!uon[u]) continue;
+                const int cw = uf[u] * 16 + fk * 4;          // column inside the tower
+                const bool cok = cw < out_w;
+                const int col = ut[u] * out_w + cw;
+                if (cok) {
+                    const float4 b = *(const float4*)(L.bias + col);
+                    gam[u] = *(const float4*)(L.gamma + col); bet[u] = *(const float4*)(L.beta + col);
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) { acc[u][mi][0] += b.x; acc[u][mi][1] += b.y; acc[u][mi][2] += b.z; acc[u][mi][3] += b.w; }
+                }
+                if (sync_stats) {
+                    const float inv = 1.0f / (float)nvalid;
+                    float mean[4], m2[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float s = 0.f;
+#pragma unroll
+                        for (int mi = 0; mi < 4; ++mi) s += (mi * 16 + fr < nvalid) ? acc[u][mi][r] : 0.f;
+#pragma unroll
+                        for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o);
+                        mean[r] = s * inv;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float s = 0.f;
+#pragma unroll
+                        for (int mi = 0; mi < 4; ++mi) {
+                            const float d = acc[u][mi][r] - mean[r];
+                            s += (mi * 16 + fr < nvalid) ? d * d : 0.f;
+                        }
+#pragma unroll
+                        for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o);
+                        m2[r] = s;
+                    }
+                    if (fr == 0 && cok) {
+                        float* o = L.part + ((int64_t)tile * ncols + col) * 2;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) tf_store_sc1(o + 2 * r, mean[r], m2[r]);
+                    }
+                }
+            }
+            unsigned* ctr = p.cnt + (size_t)(l * p.n_layers + j) * MAX_SEG + seg;
+            if (sync_stats) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its sc1 partial stores
+                __syncthreads();
+                if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            TF_STAMP();                                      // stats + drain + arrive
+            // H (pre-BatchNorm, the backward reads it) drains while the other tiles of the segment arrive
+#pragma unroll
+            for (int u = 0; u < TF_MAX_UNITS; ++u) {
+                if (!uon[u]) continue;
+                const int cw = uf[u] * 16 + fk * 4;
+                if (cw >= out_w) continue;
+                const int col = ut[u] * out_w + cw;
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    *(float4*)(L.H + (row0 + mi * 16 + fr) * ncols + col) = make_float4(acc[u][mi][0], acc[u][mi][1], acc[u][mi][2], acc[u][mi][3]);
+            }
+            // ---- statistics of the segment -------------------------------------------------------------------------------
+            if (sync_stats) {
+                if (tid == 0) {
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nt) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > TF_SPIN_LIMIT) { __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    }
+                }
+                __syncthreads();
+                TF_STAMP();                                  // H stores issued + poll
+                // merge the partials of the segment's tiles (Chan): item = (column, tile quarter q: tiles q, q+4, ...), every
+                // load of an item in flight at once, then the four quarters are combined in order -- the order of k_bn_act
+                for (int base = 0; base < 4 * ncols; base += TF_THREADS) {
+                    const int item = base + tid;
+                    const int c = item % ncols, q = item / ncols;
+                    float n = 0.f, mean = 0.f, m2 = 0.f;
+                    if (item < 4 * ncols && act[c / out_w]) {
+                        float mb[TF_MERGE_Q], qb[TF_MERGE_Q];
+#pragma unroll
+                        for (int i = 0; i < TF_MERGE_Q; ++i) {
+                            const int t = q + 4 * i;
+                            mb[i] = 0.f; qb[i] = 0.f;
+                            if (t < nt) tf_load_sc1(L.part + ((int64_t)(t0 + t) * ncols + c) * 2, mb[i], qb[i]);
+                        }
+#pragma unroll
+                        for (int i = 0; i < TF_MERGE_Q; ++i) {
+                            const int t = q + 4 * i;
+                            if (t < nt) {
+                                const float nb = t < TF_MAX_SEG_TILES ? s_tv[t] : (float)p.r.tile_valid[t0 + t];
+                                const float tot = n + nb, delta = mb[i] - mean;
+                                mean += delta * (nb / tot);
+                                m2 += qb[i] + delta * delta * (n * nb / tot);
+                                n = tot;
+                            }
+                        }
+                        for (int t = q + 4 * TF_MERGE_Q; t < nt; t += 4) {      // segments of more than 32 tiles
+                            float mbx, qbx;
+                            tf_load_sc1(L.part + ((int64_t)(t0 + t) * ncols + c) * 2, mbx, qbx);
+                            const float nb = t < TF_MAX_SEG_TILES ? s_tv[t] : (float)p.r.tile_valid[t0 + t];
+                            const float tot = n + nb, delta = mbx - mean;
+                            mean += delta * (nb / tot);
+                            m2 += qbx + delta * delta * (n * nb / tot);
+                            n = tot;
+                        }
+                    }
+                    if (item < 4 * ncols) { s_cn[q][c] = n; s_cm[q][c] = mean; s_cq[q][c] = m2; }
+                }
+                __syncthreads();
+                for (int c = tid; c < ncols; c += TF_THREADS) {
+                    float mean = 0.f, rstd = 1.f, var = 0.f;
+                    if (act[c / out_w]) {
+                        float n = 0.f, m2 = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float nb = s_cn[k][c];
+                            if (nb > 0.f) {
+                                const float tot = n + nb, delta = s_cm[k][c] - mean;
+                                mean += delta * (nb / tot);
+                                m2 += s_cq[k][c] + delta * delta * (n * nb / tot);
+                                n = tot;
+                            }
+                        }
+                        var = m2 / (float)cnt;
+                        rstd = 1.0f / sqrtf(var + BN_EPS);
+                    }
+                    s_mean[c] = mean; s_rstd[c] = rstd;
+                    if (tile == t0) {
+                        const int64_t o = (int64_t)seg * ncols + c;
+                        L.mean[o] = mean; L.rstd[o] = rstd; L.var[o] = var;
+                    }
+                }
+            } else {
+                for (int c = tid; c < ncols; c += TF_THREADS) {
+                    float mean = 0.f, rstd = 1.f, var = 0.f;
+                    if (bn && act[c / out_w]) {                          // eval mode: running statistics
+                        mean = L.rmean[c]; var = L.rvar[c];
+                        rstd = 1.0f / sqrtf(var + BN_EPS);
+                    }
+                    s_mean[c] = mean; s_rstd[c] = rstd;
+                    if (tile == t0) {
+                        const int64_t o = (int64_t)seg * ncols + c;
+                        L.mean[o] = mean; L.rstd[o] = rstd; L.var[o] = var;
+                    }
+                }
+            }
+            __syncthreads();
+            TF_STAMP();                                      // merge
+            // ---- normalise + ReLU + dropout -> Act (workspace + LDS) ----------------------------------------------------
+#pragma unroll
+            for (int u = 0; u < TF_MAX_UNITS; ++u) {
+                const int unit = wave + 4 * u;
+                if (unit >= n_units) continue;
+                const int cw = uf[u] * 16 + fk * 4;
+                if (cw >= out_w) continue;
+                const int col = ut[u] * out_w + cw;
+                float mu[4], rs[4];
+                const float ga[4] = {gam[u].x, gam[u].y, gam[u].z, gam[u].w}, be[4] = {bet[u].x, bet[u].y, bet[u].z, bet[u].w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { mu[r] = s_mean[col + r]; rs[r] = s_rstd[col + r]; }
+                const uint32_t site = (uint32_t)((L.stack * 8 + L.layer) * 64 + ut[u]);
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    const int m = mi * 16 + fr;
+                    float y[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (uon[u] && m < nvalid) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float v = acc[u][mi][r];
+                            if (bn) v = (v - mu[r]) * rs[r] * ga[r] + be[r];
+                            y[r] = v > 0.f ? v : 0.f;
+                        }
+                        if (p.train && p.thr) {
+                            const uint32_t key = dkey[mi];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) y[r] = drop_keep(key, site, (uint32_t)(cw + r), p.thr) ? y[r] * p.keep_scale : 0.f;
+                        }
+                    }
+                    const float4 o = make_float4(y[0], y[1], y[2], y[3]);
+                    *(float4*)(L.Act + (row0 + m) * ncols + col) = o;
+                    *(float4*)(actf + m * ncols + col) = o;
+                }
+            }
+            prev_cols = ncols;
+            __syncthreads();
+            TF_STAMP();                                      // normalise + Act
+            // ---- next layer of the same level: its A image is this layer's activation, tower by tower -------------------
+            if (j + 1 < p.n_layers) {
+                const TFLayer& N = p.L[l][j + 1];
+                const int npk = N.pk, nbs = 2 * npk * 512;
+                const int planes = N.ks * npk, g8 = N.in_w >> 3;
+                for (int it = tid; it < TILE_M * n_t * planes; it += TF_THREADS) {
+                    const int m = it / (n_t * planes), rem = it - m * (n_t * planes);
+                    const int t = rem / planes, pl = rem - t * planes;
+                    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    if (pl < g8) {
+                        const float* src = actf + m * ncols + t * N.in_w + pl * 8;
+                        const float4 x0 = *(const float4*)src, x1 = *(const float4*)(src + 4);
+                        v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+                    }
+                    const int blk = t * N.ks + pl / npk;
+                    tf_put8(Aimg + (size_t)blk * nbs, Aimg + (size_t)blk * nbs + npk * 512, bf3_off(TILE_M, m, pl % npk), v);
+                }
+                __syncthreads();
+            }
+        }
+    }
+    // ---------------- heads: z = cn.v[:D] + lin + act.v[D:], sigmoid, bagging BCE and its gradient ------------------------
+    {
+        const int LL = p.n_level - 1;
+        const uint8_t* act = active_level(p.mp, LL) + seg * MAX_TOWER;
+        const float cntf = (float)cnt, kact = (float)p.mp.kact[seg];
+        const float wseg = p.seg_weight ? p.seg_weight[seg] : 1.f;
+        float loss = 0.f;
+        for (int it = tid; it < TILE_M * p.ld_h; it += TF_THREADS) {
+            const int m = it / p.ld_h, i = it - m * p.ld_h;
+            const int64_t row = row0 + m;
+            float z = 0.f, pr = 0.f, dz = 0.f;
+            if (i < p.n_heads && m < nvalid && act[i]) {
+                z = p.hc[row * p.ld_h + i] + p.lin[row];
+                const float* a = actf + m * prev_cols + i * p.h_last;
+                const float* v = p.head_w + (int64_t)i * p.head_ld + p.D;
+                for (int c = 0; c < p.h_last; ++c) z += a[c] * v[c];
+                pr = 1.0f / (1.0f + __expf(-z));
+                const int b = p.r.row_sample[row];
+                if (p.probs_out) p.probs_out[(int64_t)i * p.B + b] = pr;
+                if (p.y) {
+                    const float yv = p.y[b];
+                    const float lp = fmaxf(__logf(pr), -100.f), lq = fmaxf(__logf(1.0f - pr), -100.f);
+                    loss += -(yv * lp + (1.0f - yv) * lq) / (cntf * kact);
+                    const float dp = wseg / (cntf * kact) * (pr - yv) / fmaxf((1.0f - pr) * pr, 1e-12f);
+                    dz = dp * pr * (1.0f - pr);
+                }
+            }
+            if (i < p.n_heads) { p.z[row * p.ld_h + i] = z; p.prob[row * p.ld_h + i] = pr; }
+            if (p.y) p.dz[row * p.ld_h + i] = dz;
+        }
+        if (p.loss_part) {
+            s_red[tid] = loss;
+            __syncthreads();
+            for (int o = TF_THREADS / 2; o > 0; o >>= 1) {
+                if (tid < o) s_red[tid] += s_red[tid + o];
+                __syncthreads();
+            }
+            if (tid < SUB) p.loss_part[(int64_t)tile * SUB + tid] = tid == 0 ? s_red[0] : 0.f;
+        }
+    }
+    TF_STAMP();                                            // heads
+#undef TF_STAMP
+}

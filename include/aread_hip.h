@@ -276,6 +276,12 @@ int aread_mlp_forward(const aread_model* m, const aread_mlp_call* call_host, con
 int aread_mlp_backward(const aread_model* m, const aread_mlp_call* call_host, const float* x, const float* dout,
                        float* grads, float* dx, void* stream);
 
+/* Test / A-B switch of the launch strategy (results agree to rounding): key "fused_towers" (0 = one launch per tower
+ * layer, 1 = the fused tower pyramid of csrc/tower_fused.h), "wide_gemm" (0 / 1 / 2, csrc/gemm_wide.h).  Process-wide. */
+int aread_debug_set(const char* key, int value);
+/* Diagnostics: after aread_debug_set("phase_events", 1) the forward / backward record events at their phase boundaries on
+ * the caller's stream; this returns the elapsed GPU time (ms) between consecutive boundaries of the last call. */
+int aread_debug_phase_times(float* out_ms, int n);
 /* Makes `stream` wait for the model's internal side stream (see aread_call.async_tail). */
 int aread_join(const aread_model* m, void* stream);
 /* Dense L2 terms: loss_out[0] (+)= sum_i coef[i]*w[i]^2, grads[i] += 2*coef[i]*w[i] (grads may be NULL).

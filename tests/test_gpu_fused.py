@@ -1,0 +1,102 @@
+"""GPU: the fused tower pyramid (csrc/tower_fused.h) against the layer-by-layer launch sequence of the same library, same
+parameters, same batch (split-bf16 mode): both are implementations of aread.py:152-153,263-322 + layer.py:203-229 and must
+agree to fp32 rounding, in training mode (segment-scoped batch statistics, dropout, gate statistics) and in eval mode.
+The layer-by-layer path itself is pinned to the reference goldens by test_gpu_aread.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import aread_oracle as O
+from tests.util import build_model, spec_full
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(spec, rng, B, ragged=True):
+    x = np.stack([rng.integers(0, d, B) for d in spec.field_dims]
+                 + [rng.integers(0, spec.field_dims[0] + 1, B) for _ in range(spec.n_mh_slots)], axis=1).astype(np.int32)
+    if ragged:                                   # a big segment (many tiles), small ones, a one-row one, an empty one
+        dom = rng.choice(spec.n_domain, B, p=[0.62, 0.25, 0.12, 0.01, 0.0][:spec.n_domain])
+        dom[0] = 3
+        dom[1:][dom[1:] == 3] = 0
+        x[:, spec.domain_idx] = dom
+    y = (rng.random(B) < 0.5).astype(np.float32)
+    return x, y
+
+
+def _run(model, x, y, md, fused, names):
+    from aread_amd import _lib as L
+    L.check(L.lib().aread_debug_set(b"fused_towers", int(fused)))
+    model.drop_seed = 1234
+    bufs = model.make_step_buffers(x.shape[0])
+    model.bn_stats.copy_(model._stats0); model.bn_nbt.zero_()
+    loss = model.train_step(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), bufs, masks_dev=md, want_gates=True)
+    torch.cuda.synchronize()
+    st, gate = model._last
+    err = int(st.ws.view(torch.int32)[L.lib().aread_debug_ws_offset(model._handle, st.call.B, st.call.n_seg, b"tf_err")])
+    out = {"loss": float(loss), "probs": bufs["probs"].cpu().numpy().copy(), "gdense": bufs["gdense"].cpu().numpy().copy(),
+           "gate": gate.cpu().numpy().copy(), "stats": model.bn_stats.cpu().numpy().copy(), "nbt": model.bn_nbt.cpu().numpy().copy(),
+           "gtable": model.embedding.embedding_dict.weight.grad.cpu().numpy().copy(), "err": err,
+           "rows": int(st.plan.header[2])}                      # rows of live tiles: what lies behind them is never written
+    for n, c in names:
+        out[n] = model.debug_ws(st, n, c).cpu().numpy().copy()
+    return out
+
+
+@pytest.mark.parametrize("dropout,B", [(0.0, 700), (0.2, 3000)])
+def test_fused_towers_match_layerwise_training_step(dropout, B):
+    import aread_amd
+    spec = spec_full(dropout=dropout)
+    rng = np.random.default_rng(11)
+    x, y = _batch(spec, rng, B)
+    masks = [O.random_valid_mask(spec, rng, 0.6) for _ in range(spec.n_domain)]
+    model, P = build_model(spec, 123, precision="bf16x3")
+    model.train()
+    model._stats0 = model.bn_stats.clone()
+    model.domain_mask = [[torch.tensor(np.asarray(m), dtype=torch.bool, device="cuda") for m in mk] for mk in masks]
+    md = aread_amd.pack_masks(masks, spec.n_domain, model.edge_num, "cuda")
+    names = [("In0", 3 * 64), ("tw0.0.H", 3 * 64), ("tw0.1.Act", 3 * 32), ("In1", 6 * 32), ("tw1.1.Act", 6 * 16), ("In2", 12 * 16),
+             ("tw2.0.H", 12 * 16), ("tw2.1.Act", 12 * 8), ("tw2.1.mean", 12 * 8), ("prob", 12), ("dz", 12)]
+    a = _run(model, x, y, md, 0, names)
+    b = _run(model, x, y, md, 1, names)
+    assert b["err"] == 0, "a segment hand-off of the fused kernel timed out"
+    live_seg = np.bincount(x[:, spec.domain_idx], minlength=spec.n_domain) > 0      # statistics rows of empty segments are never written
+    for n, _ in names:
+        ref, got = (a[n][:a["rows"]], b[n][:a["rows"]]) if "mean" not in n else (a[n][:spec.n_domain][live_seg], b[n][:spec.n_domain][live_seg])
+        np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(ref).max()), err_msg=n)
+    assert abs(a["loss"] - b["loss"]) <= 2e-6 * abs(a["loss"])
+    np.testing.assert_allclose(b["probs"], a["probs"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(b["gate"], a["gate"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(b["stats"], a["stats"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_array_equal(b["nbt"], a["nbt"])
+    for k in ("gdense", "gtable"):
+        d = np.abs(b[k] - a[k]).max()
+        assert d <= 5e-4 * np.abs(a[k]).max() + 1e-9, (k, d)
+
+
+def test_fused_towers_eval_and_wo_mask_forward():
+    """eval mode (running statistics, no hand-off) and the unmasked warm-up mode through the drop-in forward()."""
+    from aread_amd import _lib as L
+    spec = spec_full(dropout=0.2)
+    rng = np.random.default_rng(5)
+    x, _ = _batch(spec, rng, 500, ragged=False)
+    masks = [O.random_valid_mask(spec, rng, 0.5) for _ in range(spec.n_domain)]
+    model, P = build_model(spec, 123, precision="bf16x3")
+    model.domain_mask = [[torch.tensor(np.asarray(m), dtype=torch.bool, device="cuda") for m in mk] for mk in masks]
+    xd = torch.from_numpy(x).cuda()
+    res = {}
+    stats0 = model.bn_stats.clone()
+    for fused in (0, 1):
+        L.check(L.lib().aread_debug_set(b"fused_towers", fused))
+        model.bn_stats.copy_(stats0)                       # the train-mode forward below moves the running statistics
+        model.eval()
+        with torch.no_grad():
+            e = model(xd, mode="domain_with_mask", domain_i=2).cpu().numpy()
+            model.train(); model.drop_seed = 7
+            model.reset_for_mask_update()
+            w = model(xd, mode="wo_mask", domain_i=1, memory_gate_value=True).cpu().numpy()
+        g = torch.stack([torch.stack(v[-1:]).mean(0) for v in model.domain_tower_gate_values[1][1]]).cpu().numpy()
+        res[fused] = (e, w, g)
+    L.check(L.lib().aread_debug_set(b"fused_towers", 1))
+    for a, b in zip(res[0], res[1]):
+        np.testing.assert_allclose(b, a, rtol=1e-4, atol=1e-6)

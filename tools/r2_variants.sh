@@ -1,9 +1,10 @@
 #!/bin/bash
-# usage (GPU box): bash tools/r2_variants.sh <out-file> "<ENV1=.. ENV2=..>" ["<...>" ...]   -- step-only bench per env setting
+# usage (GPU box): bash tools/r2_variants.sh <out-file> <bench flags, e.g. --graph or --no-graph> "<ENV1=.. ENV2=..>" ["<...>" ...]
 out=$1; shift
+flags=$1; shift
 : > $out
 for v in "$@"; do
-  echo "== $v" >> $out
-  env $v timeout -k 10 200 python bench.py --step-only --steps 60 --warmup 10 --no-graph 2>>$out.err | tail -1 >> $out || exit 1
+  echo "== $v ($flags)" >> $out
+  env $v timeout -k 10 200 python bench.py --step-only --steps 60 --warmup 10 $flags 2>>$out.err | tail -1 | cut -c1-200 >> $out || exit 1
 done
 cat $out
