@@ -58,13 +58,6 @@ def parse(argv=None):
     return ap.parse_args(argv)
 
 
-def build(spec, device, seed=123, precision="f32"):
-    from tests.util import build_model
-    model, P = build_model(spec, seed, device=device, precision=precision)
-    model.train()
-    return model, P
-
-
 def log(msg):
     if int(os.environ.get("RANK", "0")) == 0:
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
@@ -205,29 +198,28 @@ def main():
         if dist.get_world_size() != args.gpus and not args.force_dp:
             raise RuntimeError(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
 
-    from oracle import aread_oracle as O          # spec + deterministic initialiser (+ cpu_baseline leg below)
     from tools import synth
     import aread_amd
     from aread_amd import _lib as L
+    from aread_amd import presets
 
-    spec = O.amazon_spec(dropout=args.dropout) if args.workload == "amazon" else O.aliccp_spec(dropout=args.dropout)
+    spec = presets.amazon_workload(args.dropout) if args.workload == "amazon" else presets.aliccp_workload(args.dropout)
     B = args.batch
     rng = np.random.default_rng(2000 + rank)
-    mrng = np.random.default_rng(2000)
-    masks = [O.random_valid_mask(spec, mrng, 0.7) for _ in range(spec.n_domain)]
     log("building model + parameters")
-    model, P = build(spec, dev, precision=args.precision)
+    model = presets.build_model(spec, dev, precision=args.precision)
+    model.train()
     log("model ready")
-    model.domain_mask = [[torch.tensor(m, dtype=torch.bool, device=dev) for m in mk] for mk in masks]
+    masks = presets.random_masks(model, 0.7, seed=2000)          # one random valid mask per domain, the same on every rank
     masks_dev = aread_amd.pack_masks(masks, spec.n_domain, model.edge_num, dev)
-    n_batches = 4
+    n_batches = 8
     batches = []
     for _ in range(n_batches):
         if args.workload == "amazon":
             x, y = synth.amazon_batch(spec, rng, B, domain=args.domain_dist)
         else:
-            x, y = synth.generic_batch(spec, rng, B, pos_rate=0.043,
-                                       domain_p=synth.ALICCP_DOMAIN_SIZE if args.domain_dist == "proportional" else None)
+            x, y = synth.generic_batch(spec, rng, B, pos_rate=spec.pos_rate,
+                                       domain_p=spec.domain_size if args.domain_dist == "proportional" else None)
         batches.append((torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev), x, y))
     xs = torch.empty_like(batches[0][0])
     ys = torch.empty_like(batches[0][1])
@@ -318,15 +310,25 @@ def main():
     # multi-GPU table variant: time both briefly (max over ranks), keep the faster
     if use_dp and args.table == "auto":
         times = {}
+        flag_group = dist.new_group(backend="gloo")          # failure flags travel on the CPU, never through a broken RCCL call
         for name in variants:
-            # no try/except here: an exception on ONE rank inside a collective would leave the other ranks waiting in it;
-            # a failing variant is fatal, the launcher (or torchrun) then ends every rank
+            # a variant that raises (on every rank alike: a bad argument, an unsupported collective) is skipped; a rank that
+            # throws alone inside a collective would leave the others waiting there -- the launcher's timeout ends that run
             dp_state["variant"] = name
-            quick(3)
-            dist.barrier()
-            tt = torch.tensor([quick()], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            times[name] = float(tt[0])
+            t_var, failed = 1e9, 0.0
+            try:
+                quick(3)
+                dist.barrier()
+                t_var = quick()
+            except Exception as exc:                 # noqa: BLE001
+                log(f"table variant {name} failed: {type(exc).__name__}: {exc}")
+                failed = 1.0
+            tt = torch.tensor([t_var, failed], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=flag_group)
+            if float(tt[1]) == 0.0:
+                times[name] = float(tt[0])
+        if not times:
+            raise RuntimeError("no multi-GPU table variant ran")
         dp_state["variant"] = min(times, key=times.get)
         dp_state["times_ms"] = {k: round(v * 1e3, 4) for k, v in times.items()}
         log(f"table variant: {dp_state['times_ms']} -> {dp_state['variant']}")
@@ -334,7 +336,7 @@ def main():
     if args.kernels_only:
         res = {"gemm_roofline": measure_gemm_kernel(model, bufs, L, B, args.precision),
                "wgrad_roofline": measure_wgrad_kernel(model, bufs, L, B, args.precision), "l2_table_roofline": measure_l2_kernel(model, bufs, L),
-               "gather_roofline": measure_gather_kernel(model, xs, bufs, L), "note": "--kernels-only profiling run"}
+               "gather_roofline": measure_gather_kernel(model, [bt[0] for bt in batches], L), "note": "--kernels-only profiling run"}
         if rank == 0:
             os.write(json_fd, (json.dumps(res) + "\n").encode())
         if use_dp:
@@ -371,16 +373,18 @@ def main():
         if use_dp:
             dist.destroy_process_group()
         return
-    # ---- roofline of the dominant kernel: the dense-L2 table sweep (read table, write dense gradient) ----
+    # ---- per-kernel rooflines, live HIP-event timing on the launch stream ------------------------------------------------
+    # `roofline` is the DOMINANT kernel of the step: the split-bf16 GEMM family (k_gemm_bf3 forward/dgrad + k_gemm_bf3_rc weight
+    # gradients) takes the largest share of the step's kernel time (profiles/r02_kernel_stats_step.txt); its largest member, the
+    # expert layer-1 forward GEMM, is reported against the dense bf16 MFMA peak.  The other entries are extra.
     gemm = measure_gemm_kernel(model, bufs, L, B, args.precision)
     wgrad = measure_wgrad_kernel(model, bufs, L, B, args.precision)
     l2pass = measure_l2_kernel(model, bufs, L)
-    gather = measure_gather_kernel(model, xs, bufs, L)
-    big_x = torch.cat([bt[0] for bt in batches] * 2, dim=0)                  # 65 536 samples: latency amortised
-    gather_big = measure_gather_kernel(model, big_x, bufs, L)
-    # `roofline` = the single most expensive kernel launch of the step (longest average duration, cf. profiles/)
-    roofline = max((gemm, wgrad, l2pass), key=lambda r: r["avg_launch_us"])
-
+    gather = measure_gather_kernel(model, [bt[0] for bt in batches], L)
+    big = [torch.cat([batches[(k + j) % n_batches][0] for j in range(8)], dim=0) for k in range(2)]   # 65 536 samples: latency amortised
+    gather_big = measure_gather_kernel(model, big, L)
+    roofline = dict(gemm)
+    roofline["share_of_step_kernel_time"] = _family_share()
     out = {
         "metric": "CTR samples/s fwd+bwd, AREAD 25-domain batch=8192" if args.workload == "amazon"
         else f"CTR samples/s fwd+bwd, AREAD 30-domain (AliCCP layout) batch={B}", "value": round(value, 1), "unit": "samples/s",
@@ -411,7 +415,7 @@ def main():
         # beyond the metric: the same step WITH the optimizer, fused (modifies the parameters: runs last)
         out["train_step_with_fused_adam"] = measure_fused_adam(model, batches, masks_dev, B, L)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(O, spec, P, masks, batches, args)
+        out["cpu_baseline"] = cpu_baseline(model, masks, batches, args)
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
@@ -435,10 +439,20 @@ def _time_kernel(fn, iters=30, warm=3):
 
 def _pmc_traffic(kernel):
     """HBM bytes per launch from the committed rocprofv3 --pmc summary (profiles/), if present."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_roofline_kernels.json")
+    for name in ("r02_pmc_roofline_kernels.json", "r01_pmc_roofline_kernels.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
+        except Exception:                                            # noqa: BLE001
+            continue
+    return None
+
+
+def _family_share():
+    """share of the step's kernel time taken by the split-bf16 GEMM family, from the committed rocprofv3 summary"""
     try:
-        with open(path) as f:
-            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
+        with open(os.path.join(ROOT, "profiles", "r02_kernel_family_share.json")) as f:
+            return json.load(f)
     except Exception:                                                # noqa: BLE001
         return None
 
@@ -463,7 +477,7 @@ def measure_gemm_kernel(model, bufs, L, B, precision):
         ach = alg / t / 1e12
         return {"kernel": "k_gemm_bf3<8> (expert layer 1 forward, split-bf16)", "bound": "mfma", "achieved": round(ach, 2),
                 "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4),
-                "issued_frac": round(3 * ach * rows / B / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "issued_frac": round(3 * ach * rows / B / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": _pmc_traffic("k_gemm_bf3<8>"),
                 "algorithmic_flops_per_launch": alg, "issued_flops_per_launch": 3 * 2.0 * D * h1 * rows,
                 "avg_launch_us": round(t * 1e6, 2), "mfma": "v_mfma_f32_16x16x32_bf16 x3 (hi*hi + hi*lo + lo*hi), f32 accumulate"}
     fn = lambda: L.check(L.lib().aread_gemm(L.ptr(A), D, 0, 1, L.ptr(W), D, 0, 1, L.ptr(out), h1, 0, L.ptr(bias), 0, rows, h1, D,
@@ -472,7 +486,7 @@ def measure_gemm_kernel(model, bufs, L, B, precision):
     ach = alg / t / 1e12
     return {"kernel": "k_gemm<8,true,true> (expert layer 1 forward)", "bound": "mfma", "achieved": round(ach, 2),
             "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4),
-            "traffic": _pmc_traffic("k_gemm<8,true,true>"), "traffic_source": "profiles/r01_pmc_roofline_kernels.json",
+            "traffic": _pmc_traffic("k_gemm<8,true,true>"), "traffic_source": "profiles/*_pmc_roofline_kernels.json",
             "algorithmic_flops_per_launch": alg, "executed_flops_per_launch": 2.0 * D * h1 * rows, "avg_launch_us": round(t * 1e6, 2),
             "mfma": "v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate)"}
 
@@ -572,28 +586,56 @@ def measure_fused_adam(model, batches, masks_dev, B, L, steps=30):
                              "avg_launch_us": round(t * 1e6, 2)}}
 
 
-def measure_gather_kernel(model, xs, bufs, L):
+def measure_gather_kernel(model, xs_list, L):
+    """k_embed_fwd on batches of the step's shape.  Three timings: `warm` = the same batch again and again (rows served from
+    L2 / Infinity Cache); `rotating` = distinct batches in turn; `cold` = a 512 MB write between two launches evicts every
+    cache level (duration = [flush + gather] loop minus [flush] loop, events on the launch stream).  The roofline entry is the
+    COLD one: algorithmic bytes (17 rows x 128 B + 68 B of ids read, 1152 B written per sample) over that time."""
     emb = model.embedding
     table = emb.embedding_dict.weight
-    B = xs.shape[0]
-    out = torch.empty((B, emb.output_dim0, emb.embed_dim), device=xs.device)
-    off = emb._offsets_dev(xs.device)
-    fn = lambda: L.check(L.lib().aread_embed_fwd(L.ptr(xs), B, xs.shape[1], L.ptr(off), L.ptr(table), table.shape[0],
-                                                 emb.embed_dim, emb.one_hot_field_num, emb.multi_hot_field_num,
-                                                 emb.seq_maxlen, emb._pool, None, B, L.ptr(out), None, L.stream()))
-    t = _time_kernel(fn)
-    per_sample = xs.shape[1] * emb.embed_dim * 4 + xs.shape[1] * 4 + emb.output_dim0 * emb.embed_dim * 4
-    read_stream = xs.shape[1] * emb.embed_dim * 4 + xs.shape[1] * 4
-    ach = per_sample * B / t / 1e9
+    B = xs_list[0].shape[0]
+    out = torch.empty((B, emb.output_dim0, emb.embed_dim), device=table.device)
+    off = emb._offsets_dev(table.device)
+
+    def launch(x):
+        L.check(L.lib().aread_embed_fwd(L.ptr(x), B, x.shape[1], L.ptr(off), L.ptr(table), table.shape[0], emb.embed_dim,
+                                        emb.one_hot_field_num, emb.multi_hot_field_num, emb.seq_maxlen, emb._pool, None, B,
+                                        L.ptr(out), None, L.stream()))
+    t_warm = _time_kernel(lambda: launch(xs_list[0]))
+    state = {"i": 0}
+
+    def rot():
+        launch(xs_list[state["i"] % len(xs_list)]); state["i"] += 1
+    t_rot = _time_kernel(rot, iters=4 * len(xs_list))
+    flush = torch.empty(128 << 20, dtype=torch.float32, device=table.device)            # 512 MB > L2 + Infinity Cache
+
+    def fl():
+        flush.fill_(1.0)
+
+    def fl_rot():
+        flush.fill_(1.0); rot()
+    t_cold = max(_time_kernel(fl_rot, iters=12, warm=2) - _time_kernel(fl, iters=12, warm=2), 1e-9)
+    del flush
+    f_in = xs_list[0].shape[1]
+    per_sample = f_in * emb.embed_dim * 4 + f_in * 4 + emb.output_dim0 * emb.embed_dim * 4
+    read_stream = f_in * emb.embed_dim * 4 + f_in * 4
+    ach = per_sample * B / t_cold / 1e9
     return {"kernel": "k_embed_fwd", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 4), "read_stream_frac": round(read_stream * B / t / 1e9 / HBM_PEAK_GBS, 4),
+            "frac": round(ach / HBM_PEAK_GBS, 4), "read_stream_frac": round(read_stream * B / t_cold / 1e9 / HBM_PEAK_GBS, 4),
+            "cache_state": "cold: 512 MB written between launches, distinct batch every launch",
             "traffic": _pmc_traffic("k_embed_fwd") if B == 8192 else None, "samples": B,
-            "algorithmic_bytes_per_launch": per_sample * B, "avg_launch_us": round(t * 1e6, 2)}
+            "algorithmic_bytes_per_launch": per_sample * B, "avg_launch_us": round(t_cold * 1e6, 2),
+            "rotating_batches_us": round(t_rot * 1e6, 2), "warm_same_batch_us": round(t_warm * 1e6, 2),
+            "warm_read_stream_frac": round(read_stream * B / t_warm / 1e9 / HBM_PEAK_GBS, 4)}
 
 
-def cpu_baseline(O, spec, P, masks, batches, args):
-    """The CPU oracle (a port of the reference path, pinned to it by tests/golden) on the host cores:
-    the same 25-domain step as 25 per-domain calls + one backward, bounded to a few steps."""
+def cpu_baseline(model, masks, batches, args):
+    """The CPU oracle (oracle/aread_oracle.py: a port of the reference path, pinned to it by tests/golden) on the host cores,
+    with THIS model's parameters: the same 25-domain step as 25 per-domain calls + one backward, bounded to a few steps."""
+    from oracle import aread_oracle as O
+    spec = O.amazon_spec(dropout=args.dropout) if args.workload == "amazon" else O.aliccp_spec(dropout=args.dropout)
+    P = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    mk = [[np.asarray(m.cpu()) for m in d] for d in masks]
     n = max(1, args.cpu_steps)
     try:
         cores = len(os.sched_getaffinity(0))
@@ -603,15 +645,15 @@ def cpu_baseline(O, spec, P, masks, batches, args):
     torch.set_num_threads(cores)
     log(f"cpu baseline (oracle) on {cores} threads ...")
     x, y = batches[0][2], batches[0][3]
-    O.step(P, spec, x[:256], y[:256], masks, drop_seed=1)             # warm the allocator / thread pool
+    O.step(P, spec, x[:256], y[:256], mk, drop_seed=1)             # warm the allocator / thread pool
     log("cpu baseline warm-up done")
     t0 = time.perf_counter()
     for i in range(n):
         xb, yb = batches[i % len(batches)][2], batches[i % len(batches)][3]
-        O.step(P, spec, xb, yb, masks, drop_seed=i)
+        O.step(P, spec, xb, yb, mk, drop_seed=i)
     dt = time.perf_counter() - t0
     return {"value": round(n * x.shape[0] / dt, 1), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} full steps of the same workload (B={x.shape[0]}, 25 per-domain calls + one backward each), "
+            "sample": f"{n} full steps of the same workload (B={x.shape[0]}, {spec.n_domain} per-domain calls + one backward each), "
                       f"{dt:.1f} s of CPU time", "ms_per_step": round(dt / n * 1e3, 1)}
 
 

@@ -220,8 +220,81 @@ def test_split_bf16_mode_within_tolerance(which):
     refl = G["multi_rand/logits"][ok]
     assert np.abs(logits_of(got[ok]) - refl).max() <= 1e-4 * max(np.abs(refl).max(), 1.0)
     np.testing.assert_allclose(float(loss), G["multi_rand/loss"][0], rtol=5e-5)
-    # gradients: BatchNorm backward on few-row segments and ReLU sign flips amplify the 4e-6 GEMM error
+    # gradients: BatchNorm backward on few-row segments and ReLU sign flips amplify the ~1e-5 product error of the split
     U.check_grads(G, "multi_rand/grad", all_grads(model), rtol=1e-2, atol_scale=1e-2)
+    # ... and norm-wise per tensor (measured: median 5e-5, 90th percentile 1e-3, worst tower tensor 5e-3; the exact-fp32
+    # mode sits at 3e-6 on the same fixtures, test_fp32_mode_gradients_norm_wise below)
+    e = _rel_l2(U.rel_l2_vs_golden(G, "multi_rand/grad", all_grads(model)))
+    assert np.median(e) <= 2e-4 and np.quantile(e, 0.9) <= 3e-3 and e.max() <= 2e-2, (np.median(e), np.quantile(e, 0.9), e.max())
+
+
+def _pre_bn_bias(name):
+    """Linear bias in front of a BatchNorm (layers.{0,4,8}.bias): the true gradient is exactly zero, every implementation
+    (the reference included) returns ~1e-10 of rounding noise there -- a relative error is meaningless"""
+    k = name.split(".")
+    return k[-1] == "bias" and "layers" in k and int(k[k.index("layers") + 1]) % 4 == 0
+
+
+def _rel_l2(d):
+    return np.array([v for n, v in d.items() if not _pre_bn_bias(n)])
+
+
+@pytest.mark.parametrize("which", ["full", "tiny"])
+def test_fp32_mode_gradients_norm_wise(which):
+    """exact-fp32 mode: every parameter gradient within 1e-4 relative L2 of the reference's (measured 3e-6 at worst)."""
+    fn, mk, seed = U.GOLDEN_MODELS[which]
+    G, spec = U.load_golden(fn), mk()
+    model, _ = U.build_model(spec, seed)
+    model.train()
+    model.domain_mask = [tmask(m) for m in U.golden_masks(spec, G, "rand")]
+    x = torch.from_numpy(G["multi_rand/x"]).cuda()
+    y = torch.from_numpy(G["multi_rand/y"].astype(np.float32)).cuda()
+    bufs = model.make_step_buffers(x.shape[0], multi_domain=True)
+    model.train_step(x, y, bufs)
+    e = _rel_l2(U.rel_l2_vs_golden(G, "multi_rand/grad", all_grads(model)))
+    assert len(e) > 100 and e.max() <= 1e-4, e.max()
+
+
+def test_baseline_size_proportional_gradients_vs_fp64_oracle():
+    """The workload bench.py runs (Amazon dims, B = 8192, domains ~ config.py:60-61) with the domains of fewer than 8 rows
+    removed (11 samples: BatchNorm over 1-3 rows is ill-conditioned in any precision): EVERY parameter gradient, norm-wise,
+    against an fp64 run of the oracle.  The fp32 oracle itself is 3e-6 (median) / 5e-4 (90th percentile) / 2e-3 (worst) away
+    from fp64 -- the per-domain BatchNorm backward amplifies rounding by ~1e3 -- so the bounds are: exact-fp32 mode the
+    oracle's own distance, split-bf16 mode that times the ~1e3 larger product error (measured median 2e-3, p90 7e-3)."""
+    import aread_amd
+    from tools import synth
+    spec = O.amazon_spec(dropout=0.0)
+    rng = np.random.default_rng(2000)
+    masks = [O.random_valid_mask(spec, rng, 0.7) for _ in range(spec.n_domain)]
+    x, y = synth.amazon_batch(spec, rng, 8192, domain="proportional")
+    cnt = np.bincount(x[:, spec.domain_idx], minlength=spec.n_domain)
+    keep = cnt[x[:, spec.domain_idx]] >= 8
+    assert keep.sum() > 0.99 * len(keep)
+    x, y = x[keep], y[keep]
+    torch.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
+    P = O.init_params(spec, 123)
+    P64 = {k: (v.double() if v.is_floating_point() else v) for k, v in P.items()}
+    r64 = O.step(P64, spec, x, y.astype(np.float64), masks)
+    for precision, med, p90, worst in (("f32", 3e-5, 3e-3, 1e-2), ("bf16x3", 1e-2, 3e-2, 0.15)):
+        model, _ = U.build_model(spec, 123, precision=precision)
+        model.train()
+        md = aread_amd.pack_masks(masks, spec.n_domain, model.edge_num, "cuda")
+        model.domain_mask = [tmask(m) for m in masks]
+        bufs = model.make_step_buffers(x.shape[0])
+        loss = model.train_step(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), bufs, masks_dev=md)
+        assert abs(float(loss) - r64["loss"]) <= 5e-5 * abs(r64["loss"]), precision
+        g = all_grads(model)
+        e = {}
+        for n, ref in r64["grads"].items():
+            ref = ref.numpy()
+            if n in g and np.linalg.norm(ref) > 0:
+                e[n] = float(np.linalg.norm(g[n].astype(np.float64) - ref) / np.linalg.norm(ref))
+        v = _rel_l2(e)
+        assert len(v) > 200
+        assert np.median(v) <= med and np.quantile(v, 0.9) <= p90 and v.max() <= worst, (precision, np.median(v), np.quantile(v, 0.9), v.max())
+        assert e["embedding.embedding_dict.weight"] <= (1e-4 if precision == "f32" else 5e-3), (precision, e["embedding.embedding_dict.weight"])
+        del model, bufs
+        torch.cuda.empty_cache()
 
 
 def test_dp_path_single_rank_matches_fused_step():
@@ -457,3 +530,62 @@ def test_multilayer_perceptron_split_bf16_backward():
     assert np.abs(gb - ga).max() <= 2e-3 * np.abs(ga).max()
     da, db = a.dense.grad.cpu().numpy(), b.dense.grad.cpu().numpy()
     assert np.linalg.norm(db - da) <= 2e-3 * np.linalg.norm(da)
+
+
+def test_aliccp_full_size_layout_properties():
+    """BASELINE configs[4] at FULL size: the AliCCP layout (23 one-hot fields, 1 140 414 table rows, D = 736, 30 domains drawn
+    ~ config.py:62-64) at B = 8192, split-bf16 mode, one step on an 'original' batch (positive rate 0.043) and one on an
+    'augmented' batch (0.13).  Too large for a full oracle step in the test budget, so:
+      * eval-mode probabilities of a 512-row sub-batch against the oracle (eval rows are independent: SURVEY 8e);
+      * size-independent properties of the training step: loss = sum_d bag_d + reg, reg against an fp64 sum, every gradient
+        finite, table-gradient rows that no sample looked up equal 2*l2*w exactly, looked-up rows differ from it, and the
+        step is bitwise reproducible (sorted segmented reduction, fixed-order partial sums)."""
+    import aread_amd
+    from tools import synth
+    spec = O.aliccp_spec(dropout=0.2)
+    rng = np.random.default_rng(5)
+    masks = [O.random_valid_mask(spec, rng, 0.7) for _ in range(spec.n_domain)]
+    model, P = U.build_model(spec, 11, precision="bf16x3")
+    md = aread_amd.pack_masks(masks, spec.n_domain, model.edge_num, "cuda")
+    model.domain_mask = [tmask(m) for m in masks]
+    x, y = synth.generic_batch(spec, rng, 8192, domain_p=synth.ALICCP_DOMAIN_SIZE, pos_rate=0.043)
+    xa, ya = synth.generic_batch(spec, rng, 8192, domain_p=synth.ALICCP_DOMAIN_SIZE, pos_rate=0.13)
+    # ---- eval forward of the whole batch (every sample under its own domain's mask) vs the oracle on 512 of its rows
+    model.eval()
+    with torch.no_grad():
+        got, _ = model(torch.from_numpy(x).cuda(), mode="with_mask")
+    order = np.argsort(x[:, spec.domain_idx], kind="stable")
+    sub = order[::16]                                               # 512 rows across all domains
+    torch.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
+    probs = O.step(P, spec, x[sub], y[sub], masks, train=False, want_grads=False, with_reg=False)["probs"]
+    mean_ref = np.nanmean(probs, axis=0)                            # mean over the active heads (aread.py:233)
+    # a domain with ONE row in the sub-batch skips BatchNorm in the oracle's per-domain call (layer.py:226), also in eval
+    # mode, while its many rows in the full batch do not: compare the others
+    dsub = x[sub, spec.domain_idx]
+    multi = np.bincount(dsub, minlength=spec.n_domain)[dsub] >= 2
+    assert multi.sum() > 480
+    np.testing.assert_allclose(got.cpu().numpy()[::16][multi], mean_ref[multi], rtol=1e-4, atol=2e-6)
+    # ---- training steps
+    model.train()
+    bufs = model.make_step_buffers(8192)
+    w = model.embedding.embedding_dict.weight.detach()
+    reg64 = spec.l2_embedding * float((w.double() ** 2).sum())
+    outs = []
+    for xb, yb in ((x, y), (xa, ya), (xa, ya)):
+        model.drop_seed = 99
+        loss = model.train_step(torch.from_numpy(xb).cuda(), torch.from_numpy(yb).cuda(), bufs, masks_dev=md)
+        torch.cuda.synchronize()
+        bag = bufs["loss"].cpu().numpy()
+        assert np.isfinite(float(loss)) and abs(float(loss) - (bag[0] + float(bufs["reg"][0]))) <= 1e-6 * abs(float(loss))
+        assert abs(bag[0] - bag[1:1 + spec.n_domain].sum()) <= 1e-5 * abs(bag[0])
+        assert float(bufs["reg"][0]) >= reg64 * (1 - 1e-5) and float(bufs["reg"][0]) <= reg64 * 1.02     # table term + the small dense terms
+        gt = model.embedding.embedding_dict.weight.grad
+        assert torch.isfinite(gt).all() and torch.isfinite(bufs["gdense"]).all()
+        touched = torch.zeros(gt.shape[0], dtype=torch.bool, device="cuda")
+        touched[torch.from_numpy(np.unique(O.index_bag(xb, spec)).astype(np.int64)).cuda()] = True
+        l2g = 2.0 * spec.l2_embedding * w
+        assert torch.equal(gt[~touched], l2g[~touched])
+        assert ((gt[touched] - l2g[touched]).abs().amax(dim=1) > 0).float().mean() > 0.99
+        outs.append((float(loss), gt.clone(), bufs["gdense"].clone()))
+    assert outs[1][0] == outs[2][0] and torch.equal(outs[1][1], outs[2][1]) and torch.equal(outs[1][2], outs[2][2])   # reproducible
+    assert outs[0][0] != outs[1][0]

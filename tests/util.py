@@ -65,6 +65,26 @@ def check_grads(G, prefix, grads, rtol=2e-4, atol_scale=2e-5, skip=(), floor=2e-
     return n
 
 
+def rel_l2_vs_golden(G, prefix, grads, skip=()):
+    """name -> ||got - ref||_2 / ||ref||_2 against packed golden gradients (full tensors, or their strided samples)."""
+    out = {}
+    for key in G:
+        full, samp = key.startswith(prefix + "/full/"), key.startswith(prefix + "/samp/")
+        if not (full or samp):
+            continue
+        name = key[len(prefix) + 6:]
+        if name in skip or name not in grads:
+            continue
+        got = np.asarray(grads[name], dtype=np.float64).reshape(-1)
+        ref = np.asarray(G[key], dtype=np.float64).reshape(-1)
+        if samp:
+            got = got[::GRAD_SAMPLE_STRIDE]
+        nrm = np.linalg.norm(ref)
+        if nrm > 0:
+            out[name] = float(np.linalg.norm(got - ref) / nrm)
+    return out
+
+
 # ---- helpers for the HIP-side model (GPU tests, smoke, bench) ---------------------------------------
 def model_config(spec, precision="f32"):
     import types

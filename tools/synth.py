@@ -7,6 +7,8 @@ AMAZON_DOMAIN_SIZE = [69360, 282546, 776105, 3001846, 88496, 449031, 2859592, 18
 ALICCP_DOMAIN_SIZE = [2695782, 1433175, 925817, 584726, 461755, 358265, 166869, 113621, 78692, 65313, 54483, 45808,
                       40975, 37939, 34079, 31703, 29551, 27084, 25027, 23464, 21764, 19857, 18390, 16712, 15852, 14914,
                       13653, 12265, 11179, 9760]                 # config.py:62-64
+# `spec` below is anything with field_dims / f_in / n_domain / itemid_idx / domain_idx / n_mh_fields / n_onehot / seq_maxlen:
+# oracle.aread_oracle.Spec (tests) or aread_amd.presets.Workload (bench.py)
 HIST_LEN_P = [0.62, 0.14, 0.07, 0.04, 0.03, 0.10]               # history length 0..5 (bundled sample histogram)
 
 
