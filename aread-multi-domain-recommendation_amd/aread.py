@@ -139,6 +139,37 @@ class _RegFn(torch.autograd.Function):
         return gtab, None, None
 
 
+class _MaskList(list):
+    """model.domain_mask: a plain list for every reader (aread.py:61), but every assignment to or through it bumps
+    owner.mask_version, so caches derived from the masks (which dense tensors receive a gradient) cannot go stale when HEMP
+    rewrites an entry in place (aread.py:330-341)."""
+
+    def __init__(self, it, owner):
+        super().__init__(it)
+        self._owner = owner
+
+    def _touch(self):
+        self._owner.__dict__["mask_version"] = self._owner.__dict__.get("mask_version", 0) + 1
+
+    def __setitem__(self, k, v):
+        super().__setitem__(k, v); self._touch()
+
+    def __delitem__(self, k):
+        super().__delitem__(k); self._touch()
+
+    def append(self, v):
+        super().append(v); self._touch()
+
+    def extend(self, it):
+        super().extend(it); self._touch()
+
+    def insert(self, i, v):
+        super().insert(i, v); self._touch()
+
+    def __reduce__(self):                     # checkpoints store a plain list (run.py:459-484 keeps 'domain_mask')
+        return (list, (list(self),))
+
+
 class AREAD(HempMixin, nn.Module):
     """Adaptive REcommendation for All Domains -- model/aread.py:15-322 on MI355X."""
 
@@ -249,6 +280,15 @@ class AREAD(HempMixin, nn.Module):
         self.drop_seed = None          # set to an int to pin the dropout stream (tests)
         self._register_state_dict_hook(AREAD._sd_hook)
         self._register_load_state_dict_pre_hook(self._load_hook)
+
+    @property
+    def domain_mask(self):
+        return self.__dict__["_domain_mask"]
+
+    @domain_mask.setter
+    def domain_mask(self, value):
+        self.__dict__["_domain_mask"] = _MaskList(value, self)
+        self.__dict__["mask_version"] = self.__dict__.get("mask_version", 0) + 1
 
     def __del__(self):
         try:

@@ -52,7 +52,16 @@ class FusedAdam:
 
     # ---- which dense tensors get a gradient (host logic, cached per mask set) -----------------------------------------
     def _present_for(self, masks):
-        key = id(masks)
+        # model.domain_mask is rewritten IN PLACE by HEMP (hemp.py update_all_mask: self.domain_mask[d] = ...), so the list's
+        # identity says nothing: the model counts every assignment (AREAD.mask_version).  Any other mask list is keyed by its
+        # content (device tensors cost a copy each: pass numpy / CPU masks, or install them as model.domain_mask).
+        m_ = self.model
+        if masks is m_.domain_mask:
+            key = ("version", m_.mask_version)
+        else:
+            key = b"|".join(b"-" if mk is None else
+                            b"".join(np.packbits(np.asarray(t.cpu() if isinstance(t, torch.Tensor) else t, dtype=bool)).tobytes() for t in mk)
+                            for mk in masks)
         if key != self._masks_key:
             m = self.model
             self._present = np.array([a or b for a, b in zip(m._presence(0, masks), m._reg_present)], dtype=bool)
@@ -138,7 +147,8 @@ class Adam(torch.optim.Optimizer):
     """Drop-in for `torch.optim.Adam(model.parameters(), lr, betas, eps, weight_decay)` in the reference's step loop
     (run.py:830-831, 680-681): the same update, but the 178 MB table and the flat dense buffer take ONE kernel launch each
     instead of ~300 per-tensor launch groups.  Construct it with the MODEL (it needs to know that the dense parameters are
-    views of one buffer); `zero_grad` / `step` / `state_dict` behave as usual.  Tensors whose grad is None are skipped
+    views of one buffer); `zero_grad` / `step` behave as usual, `state_dict` / `load_state_dict` carry the flat moment buffers
+    and torch's per-tensor step counts (a resumed run continues bit for bit).  Tensors whose grad is None are skipped
     exactly as torch does (no decay, no moment update, no step count)."""
 
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.0):
@@ -156,6 +166,39 @@ class Adam(torch.optim.Optimizer):
         c.lr, c.beta1, c.beta2, c.eps, c.weight_decay = g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"]
         c.step = int(step)
         return c
+
+    # ---- checkpointing (run.py:459-484 stores optimizer.state_dict(); harness.is_continuable does the same) -------------
+    def state_dict(self):
+        """torch's layout ({'state', 'param_groups'}) with the moments where they really live: 'state' holds the two flat
+        moment buffers of the table and of the dense parameters plus torch's step counts (one for the table, one per
+        dense tensor: tensors whose grad was None never advanced)."""
+        sd = super().state_dict()
+        sd["state"] = {"flat": {
+            "m_table": None if self._m_table is None else self._m_table.clone(),
+            "v_table": None if self._v_table is None else self._v_table.clone(),
+            "m_dense": None if self._m_dense is None else self._m_dense.clone(),
+            "v_dense": None if self._v_dense is None else self._v_dense.clone(),
+            "t_table": int(self._t_table), "t_dense": torch.from_numpy(self._t_dense.copy())}}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        flat = state_dict.get("state", {}).get("flat")
+        if flat is None:
+            raise ValueError("aread_amd.Adam.load_state_dict: not a state_dict of aread_amd.Adam (no 'flat' moment buffers)")
+        groups = state_dict["param_groups"]
+        if len(groups) != len(self.param_groups):
+            raise ValueError("loaded state dict has a different number of parameter groups")
+        for g, src in zip(self.param_groups, groups):
+            g.update({k: v for k, v in src.items() if k != "params"})
+        dev = self.model.dense.device
+        put = lambda t: None if t is None else t.detach().to(dev, torch.float32).clone()
+        self._m_table, self._v_table = put(flat["m_table"]), put(flat["v_table"])
+        self._m_dense, self._v_dense = put(flat["m_dense"]), put(flat["v_dense"])
+        self._t_table = int(flat["t_table"])
+        t = np.asarray(flat["t_dense"].cpu() if isinstance(flat["t_dense"], torch.Tensor) else flat["t_dense"], dtype=np.int64)
+        if t.shape != self._t_dense.shape:
+            raise ValueError("loaded state dict does not match this model's dense tensors")
+        self._t_dense = t.copy()
 
     def _active_mask(self, sel):
         key = sel.tobytes()

@@ -249,3 +249,114 @@ def test_dropin_adam_matches_torch_adam_on_the_reference_step_loop():
         if on:
             n = int(np.prod(shape)) if shape else 1
             assert torch.equal(d_new[off:off + n], init[off:off + n]) and torch.equal(d_ref[off:off + n], init[off:off + n]), name
+
+
+def test_dropin_adam_checkpoint_resume_is_bit_identical():
+    """aread_amd.Adam.state_dict() must carry the flat moment buffers and step counts.  Two steps, checkpoint
+    (through torch.save / torch.load like run.py:459-484), a fresh model + optimizer loaded from it, a third step: bit for bit
+    the third step of the uninterrupted run."""
+    import io
+    import aread_amd
+    from tests.test_gpu_aread import tmask
+    fn, mk, seed = U.GOLDEN_MODELS["full"]
+    G, spec = U.load_golden(fn), mk()
+    crit = torch.nn.BCELoss()
+    hyper = dict(lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-8)
+    steps = ("sparse", "rand", "ones")
+
+    def one(model, opt, mname):
+        p = f"single_{mname}"
+        d = int(G[f"{p}/domain"])
+        masks = U.golden_masks(spec, G, mname)
+        x = torch.from_numpy(G[f"{p}/x"]).cuda()
+        y = torch.from_numpy(G[f"{p}/y"].astype(np.float32)).cuda()
+        preds = model(x, mode="domain_mask_bagging", domain_i=d, current_mask=tmask(masks[d]))
+        loss = sum(crit(pr, y) for pr in preds.unbind(dim=0)) / preds.shape[0] + model.get_regularization_loss(device="cuda")
+        model.zero_grad()
+        loss.backward()
+        opt.step()
+        return float(loss.detach())
+
+    a, _ = U.build_model(spec, seed, dropout=0.0); a.train()
+    oa = aread_amd.Adam(a, **hyper)
+    for s_ in steps[:2]:
+        one(a, oa, s_)
+    buf = io.BytesIO()
+    torch.save({"state_dict": a.state_dict(), "optimizer": oa.state_dict()}, buf)
+    sd = oa.state_dict()
+    assert sd["state"]["flat"]["m_table"] is not None and int(sd["state"]["flat"]["t_table"]) == 2
+    assert len(set(sd["state"]["flat"]["t_dense"].tolist())) > 1          # tensors skipped on some steps keep their own count
+    last_a = one(a, oa, steps[2])
+    buf.seek(0)
+    ck = torch.load(buf, weights_only=False)
+    b, _ = U.build_model(spec, seed + 1, dropout=0.0); b.train()           # different initial values: everything must come from the checkpoint
+    b.load_state_dict(ck["state_dict"], strict=True)
+    ob = aread_amd.Adam(b, lr=5.0)                                          # wrong hyper-parameters too
+    ob.load_state_dict(ck["optimizer"])
+    last_b = one(b, ob, steps[2])
+    torch.cuda.synchronize()
+    assert last_a == last_b
+    assert torch.equal(a.dense.data, b.dense.data)
+    assert torch.equal(a.embedding.embedding_dict.weight.data, b.embedding.embedding_dict.weight.data)
+    assert torch.equal(oa._m_dense, ob._m_dense) and torch.equal(oa._v_table, ob._v_table)
+    import pytest
+    with pytest.raises(ValueError):
+        ob.load_state_dict(torch.optim.Adam(b.parameters()).state_dict())
+
+
+def test_fused_adam_follows_an_in_place_mask_change():
+    """HEMP rewrites model.domain_mask[d] IN PLACE; the cached 'which tensors get a gradient' set must follow.
+    Two fused steps with a regroup between them (one domain's mask replaced by one that reaches other towers) against
+    train_step + torch.optim.Adam, which sees the change through grad=None."""
+    import aread_amd
+    fn, mk, seed = U.GOLDEN_MODELS["full"]
+    G, spec = U.load_golden(fn), mk()
+    sparse, ones = U.golden_masks(spec, G, "sparse"), U.golden_masks(spec, G, "ones")
+    reach = [sum(int(np.asarray(l).any(axis=0).sum()) for l in mk_[:-1]) for mk_ in sparse]
+    sparse = [sparse[int(np.argmin(reach))]] * spec.n_domain               # every domain on the one mask that reaches the fewest towers
+    x = torch.from_numpy(G["multi_rand/x"]).cuda()
+    y = torch.from_numpy(G["multi_rand/y"].astype(np.float32)).cuda()
+    dev = lambda mk_: [torch.tensor(np.asarray(m), dtype=torch.bool, device="cuda") for m in mk_]
+
+    def fresh():
+        model, _ = U.build_model(spec, seed, dropout=0.0)
+        model.train()
+        model.domain_mask = [dev(m) for m in sparse]
+        return model
+
+    def regroup(model):
+        v = model.mask_version
+        for d in range(spec.n_domain):
+            model.domain_mask[d] = dev(ones[d])                            # what update_all_mask does (aread.py:330-341)
+        assert model.mask_version > v
+        return aread_amd.pack_masks(ones, spec.n_domain, model.edge_num, "cuda")
+
+    a = fresh()
+    opt = torch.optim.Adam(a.parameters(), **HYPER)
+    bufs = a.make_step_buffers(x.shape[0])
+    md = aread_amd.pack_masks(sparse, spec.n_domain, a.edge_num, "cuda")
+    for k in range(2):
+        a.zero_grad(set_to_none=True)
+        a.train_step(x, y, bufs, masks_dev=md)
+        opt.step()
+        if k == 0:
+            md = regroup(a)
+    b = fresh()
+    fused = aread_amd.FusedAdam(b, x.shape[0], **HYPER)
+    md = aread_amd.pack_masks(sparse, spec.n_domain, b.edge_num, "cuda")
+    p0 = fused._present_for(b.domain_mask).copy()
+    fused.step(x, y, md)
+    md = regroup(b)
+    fused.step(x, y, md)
+    p1 = fused._present_for(b.domain_mask)
+    torch.cuda.synchronize()
+    assert p1.sum() > p0.sum()                                             # the all-ones masks reach towers the sparse ones do not
+    newly = p1 & ~p0
+    assert newly.any()
+    for on, t, (name, kind, off, shape, l2) in zip(newly, fused.t_dense, b._ptensors):
+        if on:
+            assert t == 1, name                                            # first update on the second step, like torch
+            n = int(np.prod(shape)) if shape else 1
+            assert float((a.dense.data[off:off + n] - b.dense.data[off:off + n]).abs().max()) <= 5e-5, name
+    dd = (a.dense.data - b.dense.data).abs()
+    assert float(dd.mean()) <= 2e-7 and int((dd > 5e-5).sum()) <= dd.numel() // 2000
