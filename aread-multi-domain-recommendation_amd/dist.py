@@ -444,14 +444,50 @@ class ShardedTableStep:
         return self.total
 
     # ---- ZeRO-1 optimizer step (outside the fwd+bwd metric) ---------------------------------------------------------
-    def adam_step(self, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-8):
-        """Adam (run.py:830-831 hyper-parameters) on the owned table shard and dense chunk, then all_gather of the
-        dense parameters into every replica's model.dense."""
+    def adam_step(self, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-8, masks=None):
+        """Adam (run.py:830-831 hyper-parameters) on the owned table shard and dense chunk with the fused kernels of
+        csrc/optim.hip, then all_gather of the dense parameters into every replica's model.dense.  Like torch.optim.Adam
+        (and aread_amd.FusedAdam) it SKIPS the tensors whose gradient the reference's autograd leaves at None -- towers,
+        gates and heads that no domain mask reaches: no decay, no moment update, no step count -- through a per-element
+        `active` mask cut to this rank's chunk, with torch's per-tensor step counts."""
+        import numpy as np
+        from .optim import AdamCfg
+        C, L, m = self._C, self._L, self.model
+        lib = L.lib()
         if self._opt is None:
-            self._opt = torch.optim.Adam([self.shard, self.dense_chunk], lr=lr, betas=betas, eps=eps,
-                                         weight_decay=weight_decay)
-        self.shard.grad, self.dense_chunk.grad = self.gshard, self.gchunk
-        self._opt.step()
+            z = torch.zeros_like
+            self._opt = dict(m_shard=z(self.shard.data), v_shard=z(self.shard.data), m_chunk=z(self.gchunk), v_chunk=z(self.gchunk),
+                             t_table=0, t_dense=np.zeros(len(m._ptensors), dtype=np.int64), act={}, key=None, present=None)
+        o = self._opt
+
+        def cfg(step):
+            c = AdamCfg()
+            c.lr, c.beta1, c.beta2, c.eps, c.weight_decay, c.step = lr, betas[0], betas[1], eps, weight_decay, int(step)
+            return c
+        o["t_table"] += 1
+        c = cfg(o["t_table"])
+        L.check(lib.aread_adam_step(L.ptr(self.shard.data), L.ptr(self.gshard), L.ptr(o["m_shard"]), L.ptr(o["v_shard"]),
+                                    self.shard.numel(), None, C.byref(c), L.stream()))
+        masks = m.domain_mask if masks is None else masks
+        key = ("version", m.mask_version) if masks is m.domain_mask else id(masks)
+        if key != o["key"]:
+            o["present"] = np.array([a or b for a, b in zip(m._presence(0, masks), m._reg_present)], dtype=bool)
+            o["key"] = key
+        present = o["present"]
+        o["t_dense"][present] += 1
+        lo = self.p * self.chunk
+        for t in np.unique(o["t_dense"][present]):
+            sel = present & (o["t_dense"] == t)
+            k = sel.tobytes()
+            if k not in o["act"]:                                   # uint8 [chunk]: 1 on this rank's elements of the selected tensors
+                a = np.zeros(self.chunk * self.P, dtype=np.uint8)
+                for on, (name, kind, off, shape, l2) in zip(sel, m._ptensors):
+                    if on:
+                        a[off:off + (int(np.prod(shape)) if shape else 1)] = 1
+                o["act"][k] = torch.from_numpy(a[lo:lo + self.chunk].copy()).to(self.gchunk.device)
+            c = cfg(t)
+            L.check(lib.aread_adam_step(L.ptr(self.dense_chunk.data), L.ptr(self.gchunk), L.ptr(o["m_chunk"]), L.ptr(o["v_chunk"]),
+                                        self.chunk, L.ptr(o["act"][k]), C.byref(c), L.stream()))
         all_gather_flat(self.dense_pad, self.dense_chunk.data, self.group)
         self.model.dense.data.copy_(self.dense_pad[:self.model.dense.numel()])
 

@@ -192,3 +192,59 @@ def test_route_build_matches_tensor_ops(world, shape):
         assert torch.equal(uniq[:n], runiq)
         assert torch.equal(slot, rslot)
     assert int(router._ws[:router.rows_per_rank * world].sum()) == 0
+
+
+def test_sharded_adam_skips_unreached_tensors_like_torch():
+    """ShardedTableStep.adam_step must not touch tensors whose gradient the reference leaves at None (towers /
+    gates / heads no mask reaches): two steps (one rank, RCCL) against train_step + torch.optim.Adam(model.parameters()),
+    every domain on the mask that reaches the fewest towers."""
+    import torch.distributed as dist
+    import aread_amd
+    import aread_amd.dist as D
+    fn, mk, seed = U.GOLDEN_MODELS["full"]
+    G, spec = U.load_golden(fn), mk()
+    sparse = U.golden_masks(spec, G, "sparse")
+    reach = [sum(int(np.asarray(l).any(axis=0).sum()) for l in mk_[:-1]) for mk_ in sparse]
+    masks = [sparse[int(np.argmin(reach))]] * spec.n_domain
+    x, y = _rank_batch(spec, G, 0)
+    hyper = dict(lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-8)
+
+    def fresh():
+        model, _ = U.build_model(spec, seed, dropout=0.0)
+        model.train()
+        model.domain_mask = [[torch.tensor(np.asarray(m), dtype=torch.bool, device="cuda") for m in mk_] for mk_ in masks]
+        return model, aread_amd.pack_masks(masks, spec.n_domain, model.edge_num, "cuda")
+
+    a, md = fresh()
+    init = a.dense.data.clone()
+    opt = torch.optim.Adam(a.parameters(), **hyper)
+    bufs = a.make_step_buffers(x.shape[0])
+    for _ in range(2):
+        a.zero_grad(set_to_none=True)
+        a.train_step(x, y, bufs, masks_dev=md)
+        opt.step()
+    never = np.array([p.grad is None for p in a.dense_params])
+    assert never.any()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    D.FORCE_COLLECTIVES = True
+    try:
+        b, md = fresh()
+        sh = D.ShardedTableStep(b, x.shape[0])
+        for _ in range(2):
+            sh.step(x, y, md)
+            sh.adam_step(**hyper)
+        torch.cuda.synchronize()
+        for on, (name, kind, off, shape, l2) in zip(never, b._ptensors):
+            n = int(np.prod(shape)) if shape else 1
+            if on:                                                    # untouched: bit for bit the initial values, zero moments
+                assert torch.equal(b.dense.data[off:off + n], init[off:off + n]), name
+                assert float(sh._opt["m_chunk"][off:off + n].abs().max()) == 0.0, name
+        dd = (a.dense.data - b.dense.data).abs()
+        assert float(dd.mean()) <= 2e-7 and int((dd > 5e-5).sum()) <= dd.numel() // 2000
+        dw = (a.embedding.embedding_dict.weight.data - sh.full_table()).abs()
+        assert float(dw.max()) <= 3e-4 and float(dw.mean()) <= 1e-6
+    finally:
+        D.FORCE_COLLECTIVES = False
+        dist.destroy_process_group()
