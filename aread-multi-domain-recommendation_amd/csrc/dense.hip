@@ -134,6 +134,7 @@ static bool wide_any() {
 static bool use_wide(const Ctx& x, const LayerL& L) {
     wide_any();
     if (x.m->cfg.precision != 1 || g_wide_mode == 0) return false;
+    if (L.in_dim < 32 || L.out_dim < 32) return false;                    // rows of both the forward (K = in) and the dgrad (K = out) operand
     return g_wide_mode >= 2 || L.stack == 0;
 }
 

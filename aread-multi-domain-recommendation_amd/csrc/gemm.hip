@@ -136,13 +136,31 @@ int launch_gemm_bf3w(const GemmP& p_in, const WImgDesc& w, hipStream_t st) {
                  "gemm_bf3w: the statistics epilogue needs the row plan");
     AR_CHECK_ARG(w.NT == (p.N + 32 * w.NF - 1) / (32 * w.NF) && w.KS == (p.K + 31) / 32, "gemm_bf3w: weight image does not match N/K");
     const dim3 grid(w.NT, cdiv(p.M, 128), p.G);
+    // two workgroups per CU with the double-buffered A image, three with the single one: pick what keeps the launch in one
+    // residency round of the 256 CUs
+    const int tiles = (int)(grid.x * grid.y * grid.z);
+    bool adb = !(tiles > 512 && tiles <= 768);
+    if (dbg & 2) adb = false;
+    if (dbg & 4) adb = true;
+#define GW_LAUNCH(NF_)                                                                                      \
+    do {                                                                                                    \
+        if (adb) hipLaunchKernelGGL((k_gemm_bf3w<NF_, true>), grid, dim3(GEMM_THREADS), 0, st, p, w);       \
+        else hipLaunchKernelGGL((k_gemm_bf3w<NF_, false>), grid, dim3(GEMM_THREADS), 0, st, p, w);          \
+    } while (0)
     switch (w.NF) {
-        case 2: hipLaunchKernelGGL((k_gemm_bf3w<2>), grid, dim3(GEMM_THREADS), 0, st, p, w); break;
-        case 3: hipLaunchKernelGGL((k_gemm_bf3w<3>), grid, dim3(GEMM_THREADS), 0, st, p, w); break;
-        case 4: hipLaunchKernelGGL((k_gemm_bf3w<4>), grid, dim3(GEMM_THREADS), 0, st, p, w); break;
+        case 2: GW_LAUNCH(2); break;
+        case 3: GW_LAUNCH(3); break;
+        case 4: GW_LAUNCH(4); break;
         default: AR_CHECK_ARG(false, "gemm_bf3w: NF=%d", w.NF);
     }
+#undef GW_LAUNCH
     AR_LAUNCH_CHECK();
+    return AREAD_OK;
+}
+
+extern "C" int aread_debug_gemm_stamps(unsigned long long* host_out, int n) {
+    if (!host_out || n <= 0 || n > 4 * 256) return AREAD_ERR_ARG;
+    AR_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gw_stamps), (size_t)n * sizeof(unsigned long long)));
     return AREAD_OK;
 }
 

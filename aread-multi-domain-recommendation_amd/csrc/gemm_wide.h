@@ -68,14 +68,30 @@ static __global__ __launch_bounds__(256) void k_prep_wimg(const WPrepAllP a) {
 }
 
 // ---- the GEMM ------------------------------------------------------------------------------------------------
-template <int NF>
-__global__ __launch_bounds__(GEMM_THREADS, 3) void k_gemm_bf3w(const GemmP p, const WImgDesc wd) {
+typedef float gw_v4f __attribute__((ext_vector_type(4)));
+// diagnostics (AREAD_GEMM_DBG & 1): s_memrealtime stamps of four workgroups' wave 0, read back by aread_debug_gemm_stamps
+static __device__ unsigned long long g_gw_stamps[4][256];
+#define GW_STAMP()                                                                                       \
+    do {                                                                                                 \
+        if (stamping) {                                                                                  \
+            unsigned long long t_;                                                                       \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
+            if (n_st < 256) g_gw_stamps[st_slot][n_st] = t_;                                             \
+            ++n_st;                                                                                      \
+        }                                                                                                \
+    } while (0)
+
+// ADB: double-buffered A image (64 KB of LDS at NF = 4: two workgroups per CU, one barrier per k-step); without it the wave
+// holds the step's fragments in registers across a second barrier and overwrites the single A image while its MFMAs run
+// (48 KB: three workgroups per CU -- what a 608-tile launch needs to stay in one residency round).
+template <int NF, bool ADB>
+__global__ __launch_bounds__(GEMM_THREADS, ADB ? 2 : 3) void k_gemm_bf3w(const GemmP p, const WImgDesc wd) {
     constexpr int TM = 128, TN = 32 * NF;
     constexpr int A_ELEMS = TM * 32, W_ELEMS = TN * 32;                 // bf16 elements of one (hi or lo) image
-    __shared__ __attribute__((aligned(1024))) char s_lds[(2 * A_ELEMS + 4 * W_ELEMS) * 2];
-    __bf16* Ah = (__bf16*)s_lds;
-    __bf16* Al = Ah + A_ELEMS;
-    __bf16* Wb = Al + A_ELEMS;                                          // [2 buffers][hi | lo][W_ELEMS]
+    constexpr int NAB = ADB ? 2 : 1;
+    __shared__ __attribute__((aligned(1024))) char s_lds[(2 * NAB * A_ELEMS + 4 * W_ELEMS) * 2];
+    __bf16* Ab = (__bf16*)s_lds;                                        // [NAB buffers][hi | lo][A_ELEMS]
+    __bf16* Wb = Ab + 2 * NAB * A_ELEMS;                                // [2 buffers][hi | lo][W_ELEMS]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -118,40 +134,41 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void k_gemm_bf3w(const GemmP p, co
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    float4 av[4];
-    const int a_row = tid >> 3, a_kq = tid & 7;                         // + 32 rows per p
-    const bool full_m = m0 + TM <= p.M;
-    auto loadA = [&](int k0) {
+    // A rows travel global -> registers two k-steps ahead of their use (the load latency under load is ~2 us, one k-step of
+    // MFMA work is ~1 us at three workgroups per CU).  Loads are unconditional (rows and the k offset clamped into the row)
+    // so that the counted s_waitcnt below always sees exactly four younger loads; a ragged K tail is zeroed in registers.
+    gw_v4f avA[4], avB[4];
+    const int a_row = tid >> 3, a_kq = tid & 7;                         // + 32 rows per q
+    const float* a_ptr[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int r = m0 + a_row + 32 * q, k = k0 + 4 * a_kq;
-            const float* ptr = Ag + (int64_t)r * p.lda + k;
-            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((full_m || r < p.M)) {
-                if (k + 3 < p.K) t = *(const float4*)ptr;
-                else {
-                    if (k < p.K) t.x = ptr[0];
-                    if (k + 1 < p.K) t.y = ptr[1];
-                    if (k + 2 < p.K) t.z = ptr[2];
-                }
-            }
-            av[q] = t;
-        }
+    for (int q = 0; q < 4; ++q) {
+        const int r = min(m0 + a_row + 32 * q, p.M - 1);
+        a_ptr[q] = Ag + (int64_t)r * p.lda + 4 * a_kq;
+    }
+    const int k_last = (p.K + 3) / 4 * 4 - 4 - 4 * a_kq;                // clamp: the last float4 of the row's K columns (may be < 0: a_ptr holds +4*a_kq)
+    // The A loads are inline asm so that the compiler keeps no scoreboard entry for them (it would drain vmcnt, LDS-DMA
+    // included, before their first use); the counted waits at the step ends cover them, and `tie` pins the consumers of a
+    // register set behind the wait that completed it.
+    auto loadA = [&](gw_v4f (&av)[4], int k0) {
+        const int kc = min(k0, k_last);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(av[q]) : "v"(a_ptr[q] + kc) : "memory");
     };
-    auto storeA = [&]() {
+    auto tie = [&](gw_v4f (&av)[4]) { asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3])); };
+    auto storeA1 = [&](const gw_v4f (&av)[4], int k0, int buf, int q) {
+        float x[4] = {av[q][0], av[q][1], av[q][2], av[q][3]};
+        const int kleft = p.K - k0 - 4 * a_kq;                          // columns of this float4 inside K (selects, no branch)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float x[4] = {av[q].x, av[q].y, av[q].z, av[q].w};
-            bf16x4 h, l;
+        for (int i = 0; i < 4; ++i) x[i] = i < kleft ? x[i] : 0.f;
+        bf16x4 h, l;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                h[i] = (__bf16)x[i];
-                l[i] = (__bf16)(x[i] - (float)h[i]);
-            }
-            const int o = bf3_off(TM, a_row + 32 * q, a_kq >> 1) + 4 * (a_kq & 1);
-            *(bf16x4*)(Ah + o) = h;
-            *(bf16x4*)(Al + o) = l;
+        for (int i = 0; i < 4; ++i) {
+            h[i] = (__bf16)x[i];
+            l[i] = (__bf16)(x[i] - (float)h[i]);
         }
+        const int o = (ADB ? buf : 0) * 2 * A_ELEMS + bf3_off(TM, a_row + 32 * q, a_kq >> 1) + 4 * (a_kq & 1);
+        *(bf16x4*)(Ab + o) = h;
+        *(bf16x4*)(Ab + A_ELEMS + o) = l;
     };
     auto dmaW = [&](int s, int buf) {
         const __bf16* src = wsrc + (int64_t)s * 2 * W_ELEMS;
@@ -166,44 +183,79 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void k_gemm_bf3w(const GemmP p, co
     const int a_off = bf3_off(TM, wr * 64 + fr, fk);                    // + mi*16 rows: the XOR only touches row bits 1..2
     const int w_off = bf3_off(TN, wc * 16 * NF + fr, fk);
 
-    const int dbg = p.dbg;
-    if (!(dbg & 8)) loadA(0);
-    else { av[0] = av[1] = av[2] = av[3] = make_float4(1.f, 2.f, 3.f, 4.f); }
-    if (!(dbg & 16)) dmaW(0, 0);
-    for (int s = 0; s < KS; ++s) {
-        if (!(dbg & 4)) storeA();
-        __syncthreads();                                                // (waits vmcnt(0): W block s has landed)
-        if (s + 1 < KS) {
-            if (!(dbg & 8)) loadA((s + 1) * 32);
-            if (!(dbg & 16)) dmaW(s + 1, (s + 1) & 1);
-        }
+    const int lin_wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int st_slot = lin_wg == 0 ? 0 : lin_wg == 101 ? 1 : lin_wg == 303 ? 2 : lin_wg == 520 ? 3 : -1;
+    const bool stamping = (p.dbg & 1) && st_slot >= 0 && tid == 0;
+    int n_st = 0;
+    GW_STAMP();
+    // One barrier per k-step: while the MFMAs of step s run, the wave converts and stores the A rows of step s+1 into the
+    // other A buffer and the LDS-DMA brings W block s+1 into the other W buffer.  Register sets: step s+1 sits in
+    // av[(s+1)&1] (loaded two steps ago), av[s&1] is loading step s+2, and av[(s+1)&1] is reloaded with step s+3 after its store.
+    // The step is straight-line code (prefetches past the last step are clamped repeats whose results nobody reads), so the
+    // compiler can count its own waits instead of draining vmcnt.
+    auto step = [&](int s, gw_v4f (&avn)[4], gw_v4f (&avo)[4]) {
+        GW_STAMP();
+        dmaW(min(s + 1, KS - 1), (s + 1) & 1);
+        const __bf16* Ah = Ab + (ADB ? (s & 1) : 0) * 2 * A_ELEMS;
+        const __bf16* Al = Ah + A_ELEMS;
         const __bf16* Wh = Wb + (s & 1) * 2 * W_ELEMS;
         const __bf16* Wl = Wh + W_ELEMS;
-        bf16x8 ah[4], al[4];
+        bf16x8 ah[4], al[4], wh[NF], wl[NF];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             ah[j] = *(const bf16x8*)(Ah + a_off + j * 128);
             al[j] = *(const bf16x8*)(Al + a_off + j * 128);
         }
-        if (!(dbg & 2))
+        if (ADB) {
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                wh[i] = *(const bf16x8*)(Wh + w_off + i * 128);
+                wl[i] = *(const bf16x8*)(Wl + w_off + i * 128);
+            }
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave holds its A fragments: the A image is free
+        }
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
-            const bf16x8 wh = *(const bf16x8*)(Wh + w_off + i * 128);
-            const bf16x8 wl = *(const bf16x8*)(Wl + w_off + i * 128);
+            if (!ADB) {
+                wh[i] = *(const bf16x8*)(Wh + w_off + i * 128);
+                wl[i] = *(const bf16x8*)(Wl + w_off + i * 128);
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, al[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], ah[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], al[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], ah[j], acc[i][j], 0, 0, 0);
             }
         }
-        // every wave has read this step's fragments before the next step overwrites the A tile / the other W buffer.
-        // A raw barrier: __syncthreads() would also drain the LDS-DMA of the next W block that is in flight.
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < 4; ++q) storeA1(avn, (s + 1) * 32, (s + 1) & 1, q);
+        GW_STAMP();
+        loadA(avn, (s + 3) * 32);
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");     // W block s+1 and A step s+2 landed; the 4 loads above fly
+        GW_STAMP();
+        asm volatile("s_barrier" ::: "memory");
+        tie(avo);
+    };
+    dmaW(0, 0);
+    loadA(avA, 0);
+    loadA(avB, 32);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    tie(avA);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) storeA1(avA, 0, 0, q);
+    loadA(avA, 64);
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    tie(avB);
+    for (int s = 0; s < KS; s += 2) {
+        step(s, avB, avA);                                              // stores step s+1 (odd) from avB
+        if (s + 1 < KS) step(s + 1, avA, avB);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the clamped prefetches of the last steps
 
+    GW_STAMP();
     // ---- epilogue: lane holds C[m = .. + mi*16 + fr][n = .. + ni*16 + fk*4 + 0..3] ---------------------------------
-    if (!live[wr] || (dbg & 1)) return;
+    if (!live[wr]) return;
     const int nw0 = n0 + wc * 16 * NF;
     float* Cg = p.C + (int64_t)g * p.c_gs;
 #pragma unroll
@@ -229,6 +281,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void k_gemm_bf3w(const GemmP p, co
             *dst = v;
         }
     }
+    GW_STAMP();
+    if (stamping) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); GW_STAMP(); }
     if (p.stat_part) {
         // (mean, M2) over the valid rows of this wave's 64-row tile, per column: rows live on (j, fr), columns on (i, fk, reg)
         const int nv = nvalid[wr];

@@ -282,6 +282,9 @@ int aread_debug_set(const char* key, int value);
 /* Diagnostics: after aread_debug_set("phase_events", 1) the forward / backward record events at their phase boundaries on
  * the caller's stream; this returns the elapsed GPU time (ms) between consecutive boundaries of the last call. */
 int aread_debug_phase_times(float* out_ms, int n);
+/* Diagnostics: with AREAD_GEMM_DBG=1 in the environment the wide split-bf16 GEMM stamps s_memrealtime (100 MHz) at the k-step
+ * phase boundaries of four of its workgroups; copies n <= 1024 stamps ([4 workgroups][256]) of the last launch to the host. */
+int aread_debug_gemm_stamps(unsigned long long* host_out, int n);
 /* Makes `stream` wait for the model's internal side stream (see aread_call.async_tail). */
 int aread_join(const aread_model* m, void* stream);
 /* Dense L2 terms: loss_out[0] (+)= sum_i coef[i]*w[i]^2, grads[i] += 2*coef[i]*w[i] (grads may be NULL).

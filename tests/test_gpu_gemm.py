@@ -122,7 +122,8 @@ def _wide(a, b, bias, accumulate=False, C0=None, dgrad_view=False):
     G, M, K = a.shape
     N = b.shape[2] if dgrad_view else b.shape[1]
     pad = lambda n: (n + 3) // 4 * 4
-    A = np.zeros((G, M, pad(K)), np.float32); A[:, :, :K] = a
+    lda = max(pad(K), 32)                                               # the wide kernel loads whole 32-float row pieces
+    A = np.zeros((G, M, lda), np.float32); A[:, :, :K] = a
     ldc = pad(N) + 4
     C = torch.full((G, M, ldc), 7.0, device="cuda") if C0 is None else torch.from_numpy(C0).cuda()
     Ad, Bd = torch.from_numpy(A).cuda(), torch.from_numpy(np.ascontiguousarray(b)).cuda()
@@ -132,7 +133,7 @@ def _wide(a, b, bias, accumulate=False, C0=None, dgrad_view=False):
         L.check(L.lib().aread_wimg_prepare(L.ptr(Bd), K * N, 1, N, N, K, G, L.ptr(img), L.stream()))
     else:
         L.check(L.lib().aread_wimg_prepare(L.ptr(Bd), N * K, K, 1, N, K, G, L.ptr(img), L.stream()))
-    L.check(L.lib().aread_gemm_bf16x3_wide(L.ptr(Ad), pad(K), M * pad(K), L.ptr(img), L.ptr(C), ldc, M * ldc, L.ptr(bd),
+    L.check(L.lib().aread_gemm_bf16x3_wide(L.ptr(Ad), lda, M * lda, L.ptr(img), L.ptr(C), ldc, M * ldc, L.ptr(bd),
                                            N if bias is not None else 0, M, N, K, G, int(accumulate), L.stream()))
     torch.cuda.synchronize()
     return C.cpu().numpy()

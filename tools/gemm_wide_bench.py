@@ -31,6 +31,7 @@ def main():
     lib = L.lib()
     only = os.environ.get("GEMM_ONLY")
     for name, M, N, K, G in SHAPES:
+        M = int(os.environ.get("GEMM_M", M))
         if only and only not in name:
             continue
         A = torch.randn((M, G * K), device="cuda")
