@@ -264,7 +264,7 @@ static bool tower_fused_ok(const Ctx& x) {
     const aread_model_cfg& c = m->cfg;
     if (g_fused_mode < 0) {
         const char* e = getenv("AREAD_FUSED_TOWERS");
-        g_fused_mode = e ? atoi(e) : 0;
+        g_fused_mode = e ? atoi(e) : 1;                        // default on: 103 us in one launch instead of 19 launches / ~150 us
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&g_n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
             g_n_cu = 0;
@@ -279,7 +279,7 @@ static bool tower_fused_ok(const Ctx& x) {
         for (int j = 0; j < m->towers[l].n_layers; ++j) {
             const LayerL& L = m->towers[l].L[j];
             if (L.in_dim != prev_w || L.in_dim % 8 || L.out_dim % 4 || L.out_dim > 64 || L.ncols > 256) return false;
-            if (L.G * ((L.out_dim + 15) / 16) > 4 * TF_MAX_UNITS) return false;
+            if (L.G * ((L.out_dim + 15) / 16) > TF_WAVES * TF_MAX_UNITS) return false;
             prev_w = L.out_dim;
         }
     }
@@ -354,7 +354,7 @@ extern "C" int aread_forward(const aread_model* m, const aread_call* c, const fl
     mp.active = (uint8_t*)(ws + x.w.active); mp.kact = (int32_t*)(ws + x.w.kact); mp.n0act = mp.kact + MAX_SEG;
     mp.seg_dom = (int32_t*)(ws + x.w.seg_dom); mp.grp = ws + x.w.grp;
     const bool fused_towers = tower_fused_ok(x);
-    if (cfg.precision == 1 && (fused_towers || wide_any())) TRY(prepare_wimg(x, 0));   // forward weight images (wide GEMM, fused towers)
+    if (cfg.precision == 1 && wide_any()) TRY(prepare_wimg(x, 0));    // forward weight images: the wide expert GEMMs need them first
     // 1.-3. (side stream, joined before the MMoE mix: the expert layers need none of it) mask tables, row-wise trunk,
     // gate logits, cross-network part of the heads
     TRY(fork_side(x));
@@ -362,6 +362,7 @@ extern "C" int aread_forward(const aread_model* m, const aread_call* c, const fl
         const hipStream_t main_st = x.st;
         x.st = x.side;
         LAUNCH(k_mask_prep, dim3(1), dim3(256), mp);
+        if (cfg.precision == 1 && fused_towers && !wide_any()) TRY(prepare_wimg(x, 0));   // (the fused tower kernel reads them after the join)
         if (c->probs) AR_HIP(hipMemsetAsync(c->probs, 0, (size_t)m->n_heads * c->B * sizeof(float), x.st));
         if (c->train && cfg.precision == 1) { TRY(transpose_weights(x)); if (wide_any()) TRY(prepare_wimg(x, 1)); }
         RowwiseP rw = {};
@@ -427,7 +428,8 @@ extern "C" int aread_forward(const aread_model* m, const aread_call* c, const fl
     const bool side_tail = hp.loss_part || (c->train && c->update_running);
     if (side_tail) TRY(fork_side(x));
     if (hp.loss_part) {
-        hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(64), 0, x.side, ws + x.w.loss_part, c->seg_weight, c->loss_out, x.r);
+        hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(64), 0, x.side, ws + x.w.loss_part, c->seg_weight, c->loss_out, x.r,
+                           fused_towers ? (const unsigned*)(ws + x.w.tf_sync) + AREAD_MAX_LEVEL * AREAD_MAX_LAYER * MAX_SEG : nullptr);
         AR_LAUNCH_CHECK();
     }
     // 8. running statistics, in domain order

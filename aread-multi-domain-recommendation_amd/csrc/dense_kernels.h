@@ -474,8 +474,10 @@ __global__ __launch_bounds__(256) void k_heads_fwd(const HeadsP p) {
     }
 }
 
-// loss_out[0] = sum_seg w_seg * bag_seg, loss_out[1+seg] = bag_seg
-__global__ __launch_bounds__(64) void k_loss_finish(const float* loss_part, const float* seg_weight, float* loss_out, RowsP r) {
+// loss_out[0] = sum_seg w_seg * bag_seg, loss_out[1+seg] = bag_seg.  `fault` (nullable): the error word of the fused tower
+// kernel -- a segment hand-off that gave up poisons the loss with NaN, so the failure is loud without a host round trip.
+__global__ __launch_bounds__(64) void k_loss_finish(const float* loss_part, const float* seg_weight, float* loss_out, RowsP r,
+                                                    const unsigned* fault) {
     __shared__ float s_bag[MAX_SEG];
     const int seg = threadIdx.x;
     float bag = 0.f;
@@ -491,6 +493,7 @@ __global__ __launch_bounds__(64) void k_loss_finish(const float* loss_part, cons
     if (seg == 0) {
         float tot = 0.f;
         for (int s = 0; s < r.n_seg; ++s) tot += s_bag[s];
+        if (fault && *fault) tot = __builtin_nanf("");
         loss_out[0] = tot;
     }
 }

@@ -25,11 +25,15 @@
 #include "dense_kernels.h"
 #include "gemm.h"
 
-#define TF_THREADS 256
-#define TF_MAX_UNITS 4                  // units per wave and layer (16 in all)
+#ifndef TF_THREADS
+#define TF_THREADS 512                  // measured: 256 -> 152 us, 512 -> 117 us, 1024 -> 127 us (spills) for the BASELINE batch
+#endif
+#define TF_WAVES (TF_THREADS / 64)
+#define TF_DIRECT_IMG 0                 // next A image written from the normalise registers: measured 0.4 us slower per layer
+#define TF_MAX_UNITS ((16 + TF_WAVES - 1) / TF_WAVES)   // units per wave and layer (16 in all)
 #define TF_SPIN_LIMIT (1u << 22)
 #define TF_MAX_SEG_TILES 256           // tiles of one segment whose row counts are cached in LDS
-#define TF_MERGE_Q 8                   // partial loads in flight per (column, tile quarter): covers segments of <= 32 tiles
+#define TF_MERGE_Q 12                  // partial loads in flight per (column, tile group): covers segments of <= 24 tiles at two groups
 
 struct TFLayer {
     int n_t, in_w, out_w, ncols;        // towers of the level, per-tower input / output width, n_t*out_w
@@ -128,6 +132,81 @@ __global__ __launch_bounds__(TF_THREADS) void k_tower_fwd(const TFwdP p) {
         if (p.stamps && tid == 0 && n_stamp < 64) p.stamps[(size_t)tile * 64 + n_stamp] = __builtin_amdgcn_s_memrealtime(); \
         ++n_stamp;                                                                                       \
     } while (0)
+    // gates of level l's input mix: one thread per (row, tower) -> s_gate (renormalised) / s_gam (masked, HEMP statistics).
+    // They depend on the gate logits and masks only, so levels > 0 are computed between the arrive and the poll of the
+    // previous level's last hand-off, where the workgroup would otherwise idle.
+    int gates_ready = -1;
+    auto compute_gates = [&](int l) {
+        const int n_t = p.L[l][0].n_t;
+        const uint8_t* act = active_level(p.mp, l) + seg * MAX_TOWER;
+        const int n_src = l == 0 ? p.n_exp : p.n_t[l - 1];
+        const int ngate = n_t * n_src;
+        for (int it = tid; it < TILE_M * n_t; it += TF_THREADS) {
+            const int m = it / n_t, t = it - m * n_t;
+            const int64_t row = row0 + m;
+            const bool on = m < nvalid && act[t];
+            // no per-thread arrays (they would live in scratch at this register pressure): the few logits are re-read
+            // and the softmax terms recomputed with the same operations as gate_weights()
+            float* gdst = s_gate + m * ngate + t * n_src;
+            float* sdst = s_gam + m * ngate + t * n_src;
+            const bool want_am = l > 0 && p.gate_part;      // un-renormalised masked gate: HEMP statistics (aread.py:290-295)
+            if (!on) {
+                for (int s = 0; s < n_src; ++s) { gdst[s] = 0.f; if (want_am) sdst[s] = 0.f; }
+                continue;
+            }
+            const float* gl = l == 0 ? p.glogE + row * p.ld_ge + t * n_src : p.glogT + row * p.ld_gt + p.gate_off[l] + t * n_src;
+            const bool masked = l > 0 && p.mp.mode != 1;
+            const uint8_t* mk = masked ? masks + p.mask_off[l] : nullptr;
+            if (n_src <= 8) {
+                // up to 8 sources: logits and mask bytes in flight together, fully unrolled (registers, no dependent load chain)
+                float g[8];
+                bool keep[8];
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    g[s] = s < n_src ? gl[s] : -INFINITY;
+                    keep[s] = s < n_src && (!masked || mk[s * n_t + t]);
+                }
+                float mx = g[0];
+#pragma unroll
+                for (int s = 1; s < 8; ++s) mx = s < n_src ? fmaxf(mx, g[s]) : mx;
+                float den = 0.f;
+#pragma unroll
+                for (int s = 0; s < 8; ++s) { g[s] = s < n_src ? __expf(g[s] - mx) : 0.f; den += s < n_src ? g[s] : 0.f; }
+                float sum = 0.f;
+#pragma unroll
+                for (int s = 0; s < 8; ++s) { g[s] = keep[s] ? g[s] / den : 0.f; sum += s < n_src ? g[s] : 0.f; }
+                const float S = sum + GATE_EPS;
+#pragma unroll
+                for (int s = 0; s < 8; ++s)
+                    if (s < n_src) {
+                        gdst[s] = masked ? g[s] / S : g[s];
+                        if (want_am) sdst[s] = g[s];
+                    }
+                continue;
+            }
+            float mx = gl[0];
+            for (int s = 1; s < n_src; ++s) mx = fmaxf(mx, gl[s]);
+            float den = 0.f;
+            for (int s = 0; s < n_src; ++s) den += __expf(gl[s] - mx);
+            if (!masked) {                                  // MMoE / unmasked mode: plain softmax
+                for (int s = 0; s < n_src; ++s) {
+                    const float a = __expf(gl[s] - mx) / den;
+                    gdst[s] = a;
+                    if (want_am) sdst[s] = a;
+                }
+            } else {
+                float sum = 0.f;
+                for (int s = 0; s < n_src; ++s) sum += mk[s * n_t + t] ? __expf(gl[s] - mx) / den : 0.f;
+                const float S = sum + GATE_EPS;
+                for (int s = 0; s < n_src; ++s) {
+                    const float am = mk[s * n_t + t] ? __expf(gl[s] - mx) / den : 0.f;
+                    gdst[s] = am / S;
+                    if (want_am) sdst[s] = am;
+                }
+            }
+        }
+        gates_ready = l;
+    };
     TF_STAMP();                                            // 0: start
     int prev_cols = 0;                                     // width of actf (previous layer's n_t*out_w)
     for (int l = 0; l < p.n_level; ++l) {
@@ -138,29 +217,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_tower_fwd(const TFwdP p) {
         {
             const int n_src = l == 0 ? p.n_exp : p.n_t[l - 1];
             const int ngate = n_t * n_src;
-            // gates: one thread per (row, tower)
-            for (int it = tid; it < TILE_M * n_t; it += TF_THREADS) {
-                const int m = it / n_t, t = it - m * n_t;
-                const int64_t row = row0 + m;
-                const bool on = m < nvalid && act[t];
-                float a[MAX_TOWER], am[MAX_TOWER], ah[MAX_TOWER], S;
-                if (on) {
-                    if (l == 0) {                           // MMoE: plain softmax over the experts
-                        const float* gl = p.glogE + row * p.ld_ge + t * n_src;
-                        float mx = gl[0];
-                        for (int s = 1; s < n_src; ++s) mx = fmaxf(mx, gl[s]);
-                        float den = 0.f;
-                        for (int s = 0; s < n_src; ++s) den += __expf(gl[s] - mx);
-                        for (int s = 0; s < n_src; ++s) ah[s] = __expf(gl[s] - mx) / den;
-                    } else {
-                        gate_weights(p.glogT + row * p.ld_gt + p.gate_off[l] + t * n_src, n_src, masks ? masks + p.mask_off[l] : nullptr,
-                                     n_t, t, p.mp.mode, a, am, ah, &S);
-                    }
-                }
-                for (int s = 0; s < n_src; ++s) s_gate[m * ngate + t * n_src + s] = on ? ah[s] : 0.f;
-                if (l > 0 && p.gate_part)                   // un-renormalised masked gate: HEMP statistics (aread.py:290-295)
-                    for (int s = 0; s < n_src; ++s) s_gam[m * ngate + t * n_src + s] = on ? am[s] : 0.f;
-            }
+            if (gates_ready != l) compute_gates(l);          // (level 0; later levels were done while waiting for the segment)
             __syncthreads();
             TF_STAMP();                                      // gates
             if (l > 0 && p.gate_part)
@@ -181,6 +238,22 @@ __global__ __launch_bounds__(TF_THREADS) void k_tower_fwd(const TFwdP p) {
                     const float* gw = s_gate + m * ngate + t * n_src;
                     if (l == 0) {
                         const float* src = p.X + (row0 + m) * (int64_t)(n_src * p.xw) + pl * 8;
+                        if (n_src <= 4) {                    // every source row piece in flight at once
+                            float4 x0[4], x1[4];
+                            float w[4];
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) {
+                                w[s] = s < n_src ? gw[s] : 0.f;
+                                x0[s] = x1[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+                                if (w[s] != 0.f) { x0[s] = *(const float4*)(src + s * p.xw); x1[s] = *(const float4*)(src + s * p.xw + 4); }
+                            }
+#pragma unroll
+                            for (int s = 0; s < 4; ++s)
+                                if (w[s] != 0.f) {
+                                    v[0] += w[s] * x0[s].x; v[1] += w[s] * x0[s].y; v[2] += w[s] * x0[s].z; v[3] += w[s] * x0[s].w;
+                                    v[4] += w[s] * x1[s].x; v[5] += w[s] * x1[s].y; v[6] += w[s] * x1[s].z; v[7] += w[s] * x1[s].w;
+                                }
+                        } else
                         for (int s = 0; s < n_src; ++s) {
                             const float w = gw[s];
                             if (w != 0.f) {
@@ -220,7 +293,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_tower_fwd(const TFwdP p) {
             bool uon[TF_MAX_UNITS];
 #pragma unroll
             for (int u = 0; u < TF_MAX_UNITS; ++u) {
-                const int unit = wave + 4 * u;
+                const int unit = wave + TF_WAVES * u;
                 ut[u] = unit < n_units ? unit / nfr : 0;
                 uf[u] = unit < n_units ? unit - ut[u] * nfr : 0;
                 uon[u] = unit < n_units && act[ut[u]];
@@ -331,6 +404,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_tower_fwd(const TFwdP p) {
                 if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             TF_STAMP();                                      // stats + drain + arrive
+            if (j + 1 == p.n_layers && l + 1 < p.n_level) compute_gates(l + 1);
             // H (pre-BatchNorm, the backward reads it) drains while the other tiles of the segment arrive
 #pragma unroll
             for (int u = 0; u < TF_MAX_UNITS; ++u) {
@@ -355,40 +429,42 @@ __global__ __launch_bounds__(TF_THREADS) void k_tower_fwd(const TFwdP p) {
                 TF_STAMP();                                  // H stores issued + poll
                 // merge the partials of the segment's tiles (Chan): item = (column, tile quarter q: tiles q, q+4, ...), every
                 // load of an item in flight at once, then the four quarters are combined in order -- the order of k_bn_act
-                for (int base = 0; base < 4 * ncols; base += TF_THREADS) {
+                // one item per thread: (column, tile group q of nq: tiles q, q+nq, ...), every partial of the item in flight at once
+                const int nq = 4 * ncols <= TF_THREADS ? 4 : 2 * ncols <= TF_THREADS ? 2 : 1;
+                for (int base = 0; base < nq * ncols; base += TF_THREADS) {
                     const int item = base + tid;
                     const int c = item % ncols, q = item / ncols;
                     float n = 0.f, mean = 0.f, m2 = 0.f;
-                    if (item < 4 * ncols && act[c / out_w]) {
+                    if (item < nq * ncols && act[c / out_w]) {
                         float mb[TF_MERGE_Q], qb[TF_MERGE_Q];
 #pragma unroll
                         for (int i = 0; i < TF_MERGE_Q; ++i) {
-                            const int t = q + 4 * i;
+                            const int t = q + nq * i;
                             mb[i] = 0.f; qb[i] = 0.f;
                             if (t < nt) tf_load_sc1(L.part + ((int64_t)(t0 + t) * ncols + c) * 2, mb[i], qb[i]);
                         }
 #pragma unroll
                         for (int i = 0; i < TF_MERGE_Q; ++i) {
-                            const int t = q + 4 * i;
+                            const int t = q + nq * i;
                             if (t < nt) {
                                 const float nb = t < TF_MAX_SEG_TILES ? s_tv[t] : (float)p.r.tile_valid[t0 + t];
-                                const float tot = n + nb, delta = mb[i] - mean;
-                                mean += delta * (nb / tot);
-                                m2 += qb[i] + delta * delta * (n * nb / tot);
+                                const float tot = n + nb, delta = mb[i] - mean, rt = __builtin_amdgcn_rcpf(tot);
+                                mean += delta * (nb * rt);
+                                m2 += qb[i] + delta * delta * (n * nb * rt);
                                 n = tot;
                             }
                         }
-                        for (int t = q + 4 * TF_MERGE_Q; t < nt; t += 4) {      // segments of more than 32 tiles
+                        for (int t = q + nq * TF_MERGE_Q; t < nt; t += nq) {    // very long segments
                             float mbx, qbx;
                             tf_load_sc1(L.part + ((int64_t)(t0 + t) * ncols + c) * 2, mbx, qbx);
                             const float nb = t < TF_MAX_SEG_TILES ? s_tv[t] : (float)p.r.tile_valid[t0 + t];
-                            const float tot = n + nb, delta = mbx - mean;
-                            mean += delta * (nb / tot);
-                            m2 += qbx + delta * delta * (n * nb / tot);
+                            const float tot = n + nb, delta = mbx - mean, rt = __builtin_amdgcn_rcpf(tot);
+                            mean += delta * (nb * rt);
+                            m2 += qbx + delta * delta * (n * nb * rt);
                             n = tot;
                         }
                     }
-                    if (item < 4 * ncols) { s_cn[q][c] = n; s_cm[q][c] = mean; s_cq[q][c] = m2; }
+                    if (item < nq * ncols) { s_cn[q][c] = n; s_cm[q][c] = mean; s_cq[q][c] = m2; }
                 }
                 __syncthreads();
                 for (int c = tid; c < ncols; c += TF_THREADS) {
@@ -397,11 +473,11 @@ __global__ __launch_bounds__(TF_THREADS) void k_tower_fwd(const TFwdP p) {
                         float n = 0.f, m2 = 0.f;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
-                            const float nb = s_cn[k][c];
+                            const float nb = k < nq ? s_cn[k][c] : 0.f;
                             if (nb > 0.f) {
-                                const float tot = n + nb, delta = s_cm[k][c] - mean;
-                                mean += delta * (nb / tot);
-                                m2 += s_cq[k][c] + delta * delta * (n * nb / tot);
+                                const float tot = n + nb, delta = s_cm[k][c] - mean, rt = __builtin_amdgcn_rcpf(tot);
+                                mean += delta * (nb * rt);
+                                m2 += s_cq[k][c] + delta * delta * (n * nb * rt);
                                 n = tot;
                             }
                         }
@@ -431,9 +507,15 @@ __global__ __launch_bounds__(TF_THREADS) void k_tower_fwd(const TFwdP p) {
             __syncthreads();
             TF_STAMP();                                      // merge
             // ---- normalise + ReLU + dropout -> Act (workspace + LDS) ----------------------------------------------------
+            // (a following layer of the same level whose A image has no padding planes gets it directly from the registers)
+            bool direct_img = false;
+            if (j + 1 < p.n_layers) {
+                const TFLayer& N = p.L[l][j + 1];
+                direct_img = TF_DIRECT_IMG && N.ks * N.pk == (N.in_w >> 3) && (out_w & 15) == 0 && N.in_w == out_w;
+            }
 #pragma unroll
             for (int u = 0; u < TF_MAX_UNITS; ++u) {
-                const int unit = wave + 4 * u;
+                const int unit = wave + TF_WAVES * u;
                 if (unit >= n_units) continue;
                 const int cw = uf[u] * 16 + fk * 4;
                 if (cw >= out_w) continue;
@@ -462,14 +544,26 @@ __global__ __launch_bounds__(TF_THREADS) void k_tower_fwd(const TFwdP p) {
                     }
                     const float4 o = make_float4(y[0], y[1], y[2], y[3]);
                     *(float4*)(L.Act + (row0 + m) * ncols + col) = o;
-                    *(float4*)(actf + m * ncols + col) = o;
+                    if (direct_img) {
+                        // the next layer's A image straight from registers: the lane pair (fk, fk^1) holds 8 consecutive columns
+                        float v8[8];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { v8[r] = y[r]; v8[4 + r] = __shfl_xor(y[r], 16); }
+                        if (!(fk & 1)) {
+                            const TFLayer& N = p.L[l][j + 1];
+                            const int pl = cw >> 3, blk = ut[u] * N.ks + pl / N.pk, nbs = 2 * N.pk * 512;
+                            tf_put8(Aimg + (size_t)blk * nbs, Aimg + (size_t)blk * nbs + N.pk * 512, bf3_off(TILE_M, m, pl % N.pk), v8);
+                        }
+                    } else {
+                        *(float4*)(actf + m * ncols + col) = o;
+                    }
                 }
             }
             prev_cols = ncols;
             __syncthreads();
             TF_STAMP();                                      // normalise + Act
             // ---- next layer of the same level: its A image is this layer's activation, tower by tower -------------------
-            if (j + 1 < p.n_layers) {
+            if (j + 1 < p.n_layers && !direct_img) {
                 const TFLayer& N = p.L[l][j + 1];
                 const int npk = N.pk, nbs = 2 * npk * 512;
                 const int planes = N.ks * npk, g8 = N.in_w >> 3;

@@ -3,13 +3,12 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import aread_amd
-from oracle import aread_oracle as O
+from aread_amd import presets
 from tools import synth
-from tests.util import build_model
-spec = O.amazon_spec(dropout=0.2)
-rng = np.random.default_rng(0); mr = np.random.default_rng(2000)
-masks = [O.random_valid_mask(spec, mr, 0.7) for _ in range(25)]
-model, P = build_model(spec, 123); model.train()
+spec = presets.amazon_workload(0.2)
+rng = np.random.default_rng(0)
+model = presets.build_model(spec, "cuda", precision=os.environ.get("PRECISION", "bf16x3")); model.train()
+masks = presets.random_masks(model, 0.7, seed=2000)
 md = aread_amd.pack_masks(masks, 25, model.edge_num, "cuda")
 x, y = synth.amazon_batch(spec, rng, 8192)
 xs, ys = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
