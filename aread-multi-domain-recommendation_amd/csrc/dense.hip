@@ -6,6 +6,7 @@
 #include "dense_bwd_kernels.h"
 #include "gemm_wide.h"
 #include "tower_fused.h"
+#include "tower_fused_bwd.h"
 
 
 struct Ctx {
@@ -104,7 +105,7 @@ static WImgDesc wimg_desc(const Ctx& x, const LayerL& L, const LayerWs& lw, bool
     return w;
 }
 // which == 0: forward images, 1: dgrad images.  One launch for every Linear of the model's stacks, on x.st.
-static int prepare_wimg(Ctx& x, int which) {
+static int prepare_wimg(Ctx& x, int which, bool towers_only = false) {
     const aread_model* m = x.m;
     WPrepAllP a = {};
     auto add = [&](const LayerL& L, const LayerWs& lw) {
@@ -116,7 +117,8 @@ static int prepare_wimg(Ctx& x, int which) {
         else { d.N = L.in_dim; d.K = out; d.sn = 1; d.sk = L.in_dim; d.img = (__bf16*)(x.ws + lw.wimg_d); }
         d.NF = wide_nf(d.N); d.NT = (d.N + 32 * d.NF - 1) / (32 * d.NF); d.KS = (d.K + 31) / 32;
     };
-    for (int j = 0; j < m->experts.n_layers; ++j) add(m->experts.L[j], x.w.ex[j]);
+    if (!towers_only)
+        for (int j = 0; j < m->experts.n_layers; ++j) add(m->experts.L[j], x.w.ex[j]);
     if (!m->is_mlp)
         for (int l = 0; l < m->cfg.n_level; ++l)
             for (int j = 0; j < m->towers[l].n_layers; ++j) add(m->towers[l].L[j], x.w.tw[l][j]);
@@ -335,6 +337,129 @@ static int tower_fused_fwd(Ctx& x, bool want_gates) {
     return AREAD_OK;
 }
 
+
+// ---- fused tower pyramid, backward (tower_fused_bwd.h) ------------------------------------------------------------------
+static int g_fused_bwd = -1;     // AREAD_FUSED_TOWERS_BWD (default 1); needs the forward conditions (tower_fused_ok) as well
+static size_t tower_bwd_lds(const aread_model* m, TBwdP* p) {
+    const aread_model_cfg& c = m->cfg;
+    int max_blk_bytes = 0, max_cols = 0, max_ngate = 0;
+    for (int l = 0; l < c.n_level; ++l) {
+        const int n_src = l == 0 ? c.n_expert : c.n_tower[l - 1];
+        if (l > 0 && c.n_tower[l] * n_src > max_ngate) max_ngate = c.n_tower[l] * n_src;
+        for (int j = 0; j < m->towers[l].n_layers; ++j) {
+            const LayerL& L = m->towers[l].L[j];
+            const int pk = L.out_dim >= 32 ? 4 : L.out_dim / 8, ks = (L.out_dim + 31) / 32;
+            const int bytes = L.G * ks * 2 * pk * 512 * 2;
+            if (bytes > max_blk_bytes) max_blk_bytes = bytes;
+            if (L.ncols > max_cols) max_cols = L.ncols;
+            if (L.G * L.in_dim > max_cols) max_cols = L.G * L.in_dim;
+        }
+    }
+    auto up = [](size_t v) { return (v + 1023) & ~(size_t)1023; };
+    const int ldd = max_cols + 4;
+    const size_t dbytes = up((size_t)TILE_M * ldd * 4);
+    size_t scratch = (size_t)8 * 256 * 4;                                   // merge scratch
+    if ((size_t)2 * TILE_M * max_ngate * 4 > scratch) scratch = (size_t)2 * TILE_M * max_ngate * 4;   // mixing weights + dot products
+    if ((size_t)TILE_M * m->n_heads * 4 > scratch) scratch = (size_t)TILE_M * m->n_heads * 4;
+    size_t abytes = up(max_blk_bytes > (int)scratch ? (size_t)max_blk_bytes : scratch);
+    // the expert-output tile of the MMoE mix backward spans D1 + the A image region
+    const int nle = m->experts.n_layers;
+    const int wx = c.n_expert * m->experts.L[nle - 1].out_dim, ldx = wx + 4;
+    const size_t xbytes = (size_t)TILE_M * ldx * 4 + (size_t)2 * TILE_M * c.n_tower[0] * c.n_expert * 4;
+    if (xbytes > dbytes + abytes) abytes = up(xbytes - dbytes);
+    if (p) { p->lds_d0 = 0; p->lds_d1 = (int)dbytes; p->lds_aimg = (int)(2 * dbytes); p->ldd = ldd; p->ldx = ldx; }
+    return 2 * dbytes + abytes;
+}
+static bool tower_fused_bwd_ok(const Ctx& x) {
+    if (g_fused_bwd < 0) {
+        const char* e = getenv("AREAD_FUSED_TOWERS_BWD");
+        g_fused_bwd = e ? atoi(e) : 1;
+    }
+    if (!g_fused_bwd || !tower_fused_ok(x)) return false;
+    const aread_model* m = x.m;
+    const aread_model_cfg& c = m->cfg;
+    if (c.n_expert > 8) return false;
+    for (int l = 0; l < c.n_level; ++l)
+        for (int j = 0; j < m->towers[l].n_layers; ++j) {
+            const LayerL& L = m->towers[l].L[j];
+            if (L.out_dim % 8 || L.in_dim % 4 || L.in_dim > 64 || L.G * L.in_dim > 256) return false;
+            if (L.G * ((L.in_dim + 15) / 16) > TF_WAVES * TF_MAX_UNITS) return false;
+        }
+    return tower_bwd_lds(m, nullptr) + 4096 <= 160 * 1024;
+}
+
+static int wgrad(Ctx& x, const float* dY, int64_t ld_dy, int64_t dy_gs, const float* X, int64_t ldx, int64_t x_gs, int G,
+                 int M, int N, float* out, int64_t ldo, int64_t o_gs, const uint8_t* active, int64_t slab_off);
+static const uint8_t* level_active(const Ctx& x, int level);
+
+// heads backward, the tower pyramid top down, gate-mix and MMoE-mix backward in one launch; queues the same weight-gradient
+// GEMMs and bias reductions as layer_bwd
+static int tower_fused_bwd(Ctx& x, float* grads) {
+    const aread_model* m = x.m;
+    const aread_call* c = x.c;
+    const aread_model_cfg& cfg = m->cfg;
+    float* ws = x.ws;
+    const float* P = x.params;
+    const int LL = cfg.n_level - 1, nle = m->experts.n_layers;
+    TBwdP p = {};
+    p.n_level = cfg.n_level; p.n_layers = m->towers[0].n_layers; p.train = c->train; p.mode = c->mode;
+    p.seed = c->drop_seed; p.thr = x.thr; p.keep_scale = x.keep_scale;
+    for (int l = 0; l < cfg.n_level; ++l) {
+        p.n_t[l] = cfg.n_tower[l]; p.mask_off[l] = m->mask_off[l]; p.gate_off[l] = m->gate_off[l];
+        p.prevAct[l] = l > 0 ? ws + x.w.tw[l - 1][m->towers[l - 1].n_layers - 1].Act : nullptr;
+        for (int j = 0; j < m->towers[l].n_layers; ++j) {
+            const LayerL& L = m->towers[l].L[j];
+            const LayerWs& lw = x.w.tw[l][j];
+            TBLayer& T = p.L[l][j];
+            T.n_t = L.G; T.in_w = L.in_dim; T.out_w = L.out_dim; T.ncols = L.ncols;
+            T.ks = (L.out_dim + 31) / 32; T.nfr = (L.in_dim + 15) / 16; T.pk = L.out_dim >= 32 ? 4 : L.out_dim / 8;
+            T.stack = L.stack; T.layer = L.layer;
+            T.wimg = (const __bf16*)(ws + lw.wimg_d);
+            T.gamma = P + L.gamma; T.beta = P + L.beta;
+            T.H = ws + lw.H; T.mean = ws + lw.mean; T.rstd = ws + lw.rstd;
+            T.dH = ws + lw.dAct; T.bpart = ws + lw.bpart; T.cpart = ws + lw.cpart;
+        }
+    }
+    p.X = ws + x.w.ex[nle - 1].Act; p.n_exp = cfg.n_expert; p.xw = m->experts.L[nle - 1].out_dim; p.dX = ws + x.w.ex[nle - 1].dAct;
+    p.glogE = ws + x.w.glogE; p.dglogE = ws + x.w.dglogE; p.ld_ge = m->ld_ge;
+    p.glogT = ws + x.w.glogT; p.dglogT = ws + x.w.dglogT; p.ld_gt = m->ld_gt;
+    p.dz = ws + x.w.dz; p.actLast = ws + x.w.tw[LL][m->towers[LL].n_layers - 1].Act;
+    p.head_w = P + m->head_w; p.head_ld = m->head_ld; p.D = m->D; p.n_heads = m->n_heads; p.ld_h = m->ld_h; p.h_last = m->h_last;
+    p.dlin = ws + x.w.dlin; p.head_part = ws + x.w.misc_part; p.ld_hp = 1024;
+    p.cnt = (unsigned*)(ws + x.w.tf_sync) + AREAD_MAX_LEVEL * AREAD_MAX_LAYER * MAX_SEG + 64;
+    p.err = (unsigned*)(ws + x.w.tf_sync) + AREAD_MAX_LEVEL * AREAD_MAX_LAYER * MAX_SEG;     // the forward's error word
+    p.stamps = g_tf_stamps == 2 ? (unsigned long long*)(ws + x.w.gate_part) : nullptr;        // diagnostics only
+    p.r = x.r; p.mp = x.mp;
+    const int swaps = cfg.n_level * p.n_layers + (cfg.n_level - 1);
+    p.first_buf = swaps & 1;                                 // the level-0 input gradient must end up in D0 (the X tile spans D1)
+    const size_t lds = tower_bwd_lds(m, &p);
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        AR_HIP(hipFuncSetAttribute((const void*)k_tower_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set = lds;
+    }
+    AR_HIP(hipMemsetAsync(p.cnt, 0, (size_t)(AREAD_MAX_LEVEL * AREAD_MAX_LAYER * MAX_SEG) * sizeof(unsigned), x.st));
+    hipLaunchKernelGGL(k_tower_bwd, dim3(x.n_tiles), dim3(TF_THREADS), lds, x.st, p);
+    AR_LAUNCH_CHECK();
+    // the side-stream consumers of what the kernel wrote: bias / gamma / beta reductions and weight gradients, tower by tower
+    for (int l = LL; l >= 0; --l) {
+        const StackL& S = m->towers[l];
+        for (int j = S.n_layers - 1; j >= 0; --j) {
+            const LayerL& L = S.L[j];
+            const LayerWs& lw = x.w.tw[l][j];
+            const float* in = j == 0 ? ws + x.w.In[l] : ws + x.w.tw[l][j - 1].Act;
+            AR_CHECK_ARG(x.bias.n < MAX_BN_LAYERS_DECL, "too many layers");
+            BiasOne& bo = x.bias.d[x.bias.n++];
+            bo.cpart = ws + lw.cpart; bo.bpart = ws + lw.bpart; bo.db = grads + L.b; bo.dgamma = grads + L.gamma; bo.dbeta = grads + L.beta;
+            bo.ncols = L.ncols; bo.h = L.out_dim; bo.level = l;
+            const uint8_t* act = L.G > 1 ? level_active(x, l) : nullptr;
+            TRY(wgrad(x, ws + lw.dAct, L.ncols, L.out_dim, in, L.in_ld, L.in_gs, L.G, L.out_dim, L.in_dim, grads + L.w, L.in_dim,
+                      (int64_t)L.out_dim * L.in_dim, act, x.w.slab_tw[l][j]));
+        }
+    }
+    return AREAD_OK;
+}
+
 extern "C" int aread_forward(const aread_model* m, const aread_call* c, const float* e_in, void* stream) {
     Ctx x;
     TRY(make_ctx(m, c, stream, &x));
@@ -364,7 +489,11 @@ extern "C" int aread_forward(const aread_model* m, const aread_call* c, const fl
         LAUNCH(k_mask_prep, dim3(1), dim3(256), mp);
         if (cfg.precision == 1 && fused_towers && !wide_any()) TRY(prepare_wimg(x, 0));   // (the fused tower kernel reads them after the join)
         if (c->probs) AR_HIP(hipMemsetAsync(c->probs, 0, (size_t)m->n_heads * c->B * sizeof(float), x.st));
-        if (c->train && cfg.precision == 1) { TRY(transpose_weights(x)); if (wide_any()) TRY(prepare_wimg(x, 1)); }
+        if (c->train && cfg.precision == 1) {
+            TRY(transpose_weights(x));
+            if (wide_any()) TRY(prepare_wimg(x, 1));
+            else if (tower_fused_bwd_ok(x)) TRY(prepare_wimg(x, 1, true));   // dgrad images of the tower layers
+        }
         RowwiseP rw = {};
         rw.e = e_in; rw.cn = ws + x.w.cn; rw.lin = ws + x.w.lin; rw.xw = ws + x.w.xw; rw.q = ws + x.w.q; rw.grp = ws + x.w.grp;
         rw.lin_w = P + m->lin_w; rw.lin_b = P + m->lin_b; rw.cn_w = P + m->cn_w; rw.cn_b = P + m->cn_b;
@@ -594,6 +723,20 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     hp.prob = ws + x.w.prob; hp.dz = ws + x.w.dz; hp.n_heads = m->n_heads; hp.ld_h = m->ld_h; hp.B = c->B;
     hp.y = c->y; hp.seg_weight = c->seg_weight; hp.dprobs = dprobs; hp.level = LL; hp.r = x.r; hp.mp = x.mp;
     if (dprobs || !c->y) LAUNCH(k_heads_dz, dim3(x.n_tiles * SUB), dim3(256), hp);   // else: fused into k_heads_fwd
+    const bool fused_bwd = c->train && tower_fused_bwd_ok(x);
+    const int nle = m->experts.n_layers;
+    if (fused_bwd) {
+        // dcn = dz V[:, :D]   and (queued for the side stream)   dV[:, :D] = dz^T cn
+        TRY(simple_gemm(x, ws + x.w.dz, m->ld_h, true, P + m->head_w, m->head_ld, false, ws + x.w.dcn, D, nullptr, (int)x.rows, D,
+                        m->n_heads, 0, 1));
+        TRY(wgrad(x, ws + x.w.dz, m->ld_h, 0, ws + x.w.cn, D, 0, 1, m->n_heads, D, grads + m->head_w, m->head_ld, 0, nullptr, x.w.slab_head));
+        AR_CHECK_ARG(m->n_heads * m->h_last <= 1024, "aread_backward: n_heads*h_last too large");
+        phase_mark(x.st, 4);
+        // 2.-4. heads backward, tower pyramid, gate-mix and MMoE-mix backward: one launch
+        TRY(tower_fused_bwd(x, grads));
+        phase_mark(x.st, 5);
+        if (m->gate_rows == 0) AR_HIP(hipMemsetAsync(ws + x.w.dq, 0, (size_t)x.rows * 2 * E * sizeof(float), x.st));
+    } else {
     // 2. heads backward
     const LayerWs& last = x.w.tw[LL][m->towers[LL].n_layers - 1];
     HeadsBwdP hb = {};
@@ -629,13 +772,13 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     phase_mark(x.st, 5);
     if (m->gate_rows == 0) AR_HIP(hipMemsetAsync(ws + x.w.dq, 0, (size_t)x.rows * 2 * E * sizeof(float), x.st));
     // 4. MMoE mix backward
-    const int nle = m->experts.n_layers;
     const LayerL& EL = m->experts.L[nle - 1];
     Mix0BwdP m0 = {};
     m0.glog = ws + x.w.glogE; m0.dglog = ws + x.w.dglogE; m0.ld_g = m->ld_ge; m0.X = ws + x.w.ex[nle - 1].Act;
     m0.dU = ws + x.w.dIn[0]; m0.dX = ws + x.w.ex[nle - 1].dAct; m0.n_t = cfg.n_tower[0]; m0.n_exp = cfg.n_expert; m0.h = EL.out_dim;
     m0.r = x.r; m0.mp = x.mp;
     LAUNCH(k_mix0_bwd, dim3(x.n_tiles * SUB), dim3(256), m0);
+    }
     // ---- side batch A (ONE fork): everything off the critical path that the tower / gate backward has made ready -------------
     const int n_ge = cfg.n_tower[0] * cfg.n_expert;
     const hipStream_t main_st = x.st;
@@ -737,6 +880,7 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
 extern "C" int aread_debug_set(const char* key, int value) {
     AR_CHECK_ARG(key != nullptr, "aread_debug_set: null key");
     if (!strcmp(key, "fused_towers")) g_fused_mode = value;
+    else if (!strcmp(key, "fused_towers_bwd")) g_fused_bwd = value;
     else if (!strcmp(key, "wide_gemm")) g_wide_mode = value;
     else if (!strcmp(key, "tf_stamps")) g_tf_stamps = value;
     else if (!strcmp(key, "phase_events")) g_phase_on = value;

@@ -311,6 +311,7 @@ extern "C" int64_t aread_debug_ws_offset(const aread_model* m, int64_t B, int n_
     int l, j;
     char f[16];
     if (!strcmp(name, "misc_part")) return w.misc_part;
+    if (!strcmp(name, "gate_part")) return w.gate_part;
     if (!strcmp(name, "tf_err")) return w.tf_sync + AREAD_MAX_LEVEL * AREAD_MAX_LAYER * MAX_SEG;
     if (!strcmp(name, "cn")) return w.cn;
     if (!strcmp(name, "lin")) return w.lin;

@@ -24,9 +24,10 @@ def _batch(spec, rng, B, ragged=True):
     return x, y
 
 
-def _run(model, x, y, md, fused, names):
+def _run(model, x, y, md, fused, names, fused_bwd=None):
     from aread_amd import _lib as L
     L.check(L.lib().aread_debug_set(b"fused_towers", int(fused)))
+    L.check(L.lib().aread_debug_set(b"fused_towers_bwd", int(fused if fused_bwd is None else fused_bwd)))
     model.drop_seed = 1234
     bufs = model.make_step_buffers(x.shape[0])
     model.bn_stats.copy_(model._stats0); model.bn_nbt.zero_()
@@ -72,6 +73,35 @@ def test_fused_towers_match_layerwise_training_step(dropout, B):
     for k in ("gdense", "gtable"):
         d = np.abs(b[k] - a[k]).max()
         assert d <= 5e-4 * np.abs(a[k]).max() + 1e-9, (k, d)
+
+
+@pytest.mark.parametrize("dropout,B,p_active", [(0.0, 700, 0.6), (0.2, 3000, 0.6), (0.2, 1500, 0.3)])
+def test_fused_tower_backward_matches_layerwise(dropout, B, p_active):
+    """csrc/tower_fused_bwd.h against the layer-by-layer backward on the same (fused) forward: every buffer the side stream
+    and the expert backward read -- dH of every tower layer, the gate-logit gradients, dX, dlin -- and the final gradients."""
+    import aread_amd
+    spec = spec_full(dropout=dropout)
+    rng = np.random.default_rng(23)
+    x, y = _batch(spec, rng, B)
+    masks = [O.random_valid_mask(spec, rng, p_active) for _ in range(spec.n_domain)]
+    model, P = build_model(spec, 321, precision="bf16x3")
+    model.train()
+    model._stats0 = model.bn_stats.clone()
+    model.domain_mask = [[torch.tensor(np.asarray(m), dtype=torch.bool, device="cuda") for m in mk] for mk in masks]
+    md = aread_amd.pack_masks(masks, spec.n_domain, model.edge_num, "cuda")
+    names = [("tw2.1.dAct", 12 * 8), ("tw2.0.dAct", 12 * 16), ("tw1.1.dAct", 6 * 16), ("tw1.0.dAct", 6 * 32), ("tw0.1.dAct", 3 * 32),
+             ("tw0.0.dAct", 3 * 64), ("ex2.dAct", 4 * 64), ("dcn", None)]
+    names = [(n, c) for n, c in names if c is not None]
+    a = _run(model, x, y, md, 1, names, fused_bwd=0)
+    b = _run(model, x, y, md, 1, names, fused_bwd=1)
+    assert a["err"] == 0 and b["err"] == 0, "a segment hand-off timed out"
+    for n, _ in names:
+        ref, got = a[n][:a["rows"]], b[n][:a["rows"]]
+        np.testing.assert_allclose(got, ref, rtol=5e-4, atol=2e-5 * max(1e-30, np.abs(ref).max()), err_msg=n)
+    assert abs(a["loss"] - b["loss"]) == 0.0
+    for k in ("gdense", "gtable"):
+        d = np.abs(b[k] - a[k]).max()
+        assert d <= 2e-4 * np.abs(a[k]).max() + 1e-12, (k, d)
 
 
 def test_fused_towers_eval_and_wo_mask_forward():
