@@ -44,7 +44,9 @@ class Call(C.Structure):
                 ("update_running", C.c_int32), ("domain", C.c_int32), ("drop_seed", C.c_uint32),
                 ("plan", C.c_void_p), ("masks", C.c_void_p), ("params", C.c_void_p), ("stats", C.c_void_p),
                 ("nbt", C.c_void_p), ("ws", C.c_void_p), ("probs", C.c_void_p), ("gate_stats", C.c_void_p),
-                ("y", C.c_void_p), ("seg_weight", C.c_void_p), ("loss_out", C.c_void_p), ("async_tail", C.c_int32)]
+                ("y", C.c_void_p), ("seg_weight", C.c_void_p), ("loss_out", C.c_void_p), ("async_tail", C.c_int32),
+                ("l2_table", C.c_void_p), ("l2_n", C.c_int64), ("l2_coef", C.c_float), ("l2_workgroups", C.c_int32),
+                ("l2_grad", C.c_void_p), ("l2_partial", C.c_void_p), ("l2_reg_out", C.c_void_p), ("l2_dense_coef", C.c_void_p)]
 
 
 for _n, _r, _a in [
@@ -277,6 +279,8 @@ class AREAD(HempMixin, nn.Module):
         import os
         self.l2_pass_workgroups = int(os.environ.get("AREAD_L2_WG", "0"))   # width of the table L2 sweep inside the fused step
         self.l2_pass_early = os.environ.get("AREAD_L2_EARLY", "0") == "1"    # A/B: the sweep right after the row plan (round 1)
+        self.l2_pass_in_backward = os.environ.get("AREAD_L2_IN_BWD", "1") == "1"   # default: issued by aread_backward beside the tower backward
+        self.l2_dense_in_backward = os.environ.get("AREAD_L2_DENSE_IN_BWD", "0") == "1"   # A/B only
         self.drop_seed = None          # set to an int to pin the dropout stream (tests)
         self._register_state_dict_hook(AREAD._sd_hook)
         self._register_load_state_dict_pre_hook(self._load_hook)
@@ -654,18 +658,27 @@ class AREAD(HempMixin, nn.Module):
         st, gate = self._run(x, 0, n_seg, domain_i, masks_dev, want_gates, y=y, seg_weight=seg_weight,
                              loss_out=bufs["loss"], ws=bufs["ws"], probs=bufs["probs"], e=bufs["e"], plan=plan,
                              e_ready=e_ready, async_fwd=True)
-        if not self.l2_pass_early:
+        in_bwd = self.l2_pass_in_backward and not self.l2_pass_early and table_pass and with_reg
+        if not self.l2_pass_early and not in_bwd:
             l2_pass()
         if presort:
             side.wait_event(plan_ready)
             with torch.cuda.stream(side):
                 self.embedding.sort_lookups(x, plan.sample_row)
         st.call.async_tail = 3          # parameter gradients finish on the library's side stream: see step_finish
+        if in_bwd:                      # the table L2 sweep is issued by the backward, beside the latency-bound tower backward
+            st.call.l2_table, st.call.l2_n, st.call.l2_coef = L.ptr(table), table.numel(), self.l2_reg_embedding
+            st.call.l2_workgroups = self.l2_pass_workgroups or 256   # one workgroup per CU: leaves room for the tower kernel's
+            st.call.l2_grad, st.call.l2_partial, st.call.l2_reg_out = L.ptr(gtable), L.ptr(part), L.ptr(bufs["reg"])
+            if with_dense_l2 and self.l2_dense_in_backward:   # (measured 40 us SLOWER: the extra cross-stream hop costs more than the two kernels)
+                st.call.l2_dense_coef = L.ptr(self._l2_coef(self.dense.device))
         L.check(lib.aread_backward(self._handle, C.byref(st.call), L.ptr(st.e), None, L.ptr(bufs["gdense"]),
                                    L.ptr(bufs["de"]), L.stream()))
         st.call.async_tail = 0
+        st.call.l2_table = None
+        st.call.l2_dense_coef = None
         main.wait_stream(side)          # table L2 pass + index sort
-        self._pending_dense_l2 = bool(with_reg and with_dense_l2)
+        self._pending_dense_l2 = bool(with_reg and with_dense_l2) and not (in_bwd and self.l2_dense_in_backward)
         self._last = (st, gate)
         return st
 

@@ -725,6 +725,17 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     if (dprobs || !c->y) LAUNCH(k_heads_dz, dim3(x.n_tiles * SUB), dim3(256), hp);   // else: fused into k_heads_fwd
     const bool fused_bwd = c->train && tower_fused_bwd_ok(x);
     const int nle = m->experts.n_layers;
+    auto table_l2_pass = [&]() -> int {
+        // the caller's embedding-table L2 sweep, released now: it runs beside the tower backward (a chain of latency-bound
+        // phases that leaves the HBM idle) on the second side stream, which joins the main stream at the end of the call
+        if (!c->l2_table) return AREAD_OK;
+        hipEvent_t ev = x.m->ev[x.ev_next++ % (x.m->n_ev - 1)];
+        AR_HIP(hipEventRecord(ev, x.st));
+        AR_HIP(hipStreamWaitEvent(m->side2, ev, 0));
+        TRY(aread_l2_table_throttled(c->l2_table, c->l2_n, c->l2_coef, 1.0f, c->l2_grad, c->l2_partial, c->l2_workgroups, m->side2));
+        TRY(aread_l2_finish(c->l2_partial, aread_l2_partials(), c->l2_coef, c->l2_reg_out, 0, m->side2));
+        return AREAD_OK;
+    };
     if (fused_bwd) {
         // dcn = dz V[:, :D]   and (queued for the side stream)   dV[:, :D] = dz^T cn
         TRY(simple_gemm(x, ws + x.w.dz, m->ld_h, true, P + m->head_w, m->head_ld, false, ws + x.w.dcn, D, nullptr, (int)x.rows, D,
@@ -733,6 +744,7 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
         AR_CHECK_ARG(m->n_heads * m->h_last <= 1024, "aread_backward: n_heads*h_last too large");
         phase_mark(x.st, 4);
         // 2.-4. heads backward, tower pyramid, gate-mix and MMoE-mix backward: one launch
+        TRY(table_l2_pass());
         TRY(tower_fused_bwd(x, grads));
         phase_mark(x.st, 5);
         if (m->gate_rows == 0) AR_HIP(hipMemsetAsync(ws + x.w.dq, 0, (size_t)x.rows * 2 * E * sizeof(float), x.st));
@@ -750,6 +762,7 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
                     m->n_heads, 0, 1));
     TRY(wgrad(x, ws + x.w.dz, m->ld_h, 0, ws + x.w.cn, D, 0, 1, m->n_heads, D, grads + m->head_w, m->head_ld, 0, nullptr, x.w.slab_head));
     phase_mark(x.st, 4);
+    TRY(table_l2_pass());
     // 3. tower pyramid, top down (the weight gradients queue up)
     for (int l = LL; l >= 0; --l) {
         const StackL& S = m->towers[l];
@@ -866,6 +879,14 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     x.st = x.side;
     TRY(flush_reductions(x));
     x.st = main_st;
+    if (c->l2_table && c->l2_dense_coef) {
+        // dense L2 terms behind the last reduction, on the SECOND side stream (it already holds the table term and the row-wise
+        // parameter gradients in stream order, and it only ever waits on the first side stream -- never the reverse: see 4a)
+        hipEvent_t e3 = x.m->ev[x.ev_next++ % (x.m->n_ev - 1)];
+        AR_HIP(hipEventRecord(e3, x.side));
+        AR_HIP(hipStreamWaitEvent(m->side2, e3, 0));
+        TRY(aread_l2_dense(x.params, c->l2_dense_coef, m->n_params, grads, c->l2_reg_out, 1, m->side2));
+    }
     {   // the second side stream (row-wise parameter gradients, finished long ago) joins the main stream
         hipEvent_t e2 = x.m->ev[x.ev_next++ % (x.m->n_ev - 1)];
         AR_HIP(hipEventRecord(e2, rw_stream));

@@ -411,6 +411,8 @@ def main():
         "loss": round(loss, 6),
     }
     if world == 1 and not use_dp:
+        if args.precision == "bf16x3":
+            out["tower_kernels"] = measure_tower_kernels(model, batches, bufs, masks_dev, B, L)
         out["forward_only"] = measure_forward_only(model, batches, bufs, masks_dev, B)      # BASELINE configs[1]
         # beyond the metric: the same step WITH the optimizer, fused (modifies the parameters: runs last)
         out["train_step_with_fused_adam"] = measure_fused_adam(model, batches, masks_dev, B, L)
@@ -523,6 +525,40 @@ def measure_wgrad_kernel(model, bufs, L, B, precision):
             "traffic": _pmc_traffic("k_gemm<6,false,false>"), "algorithmic_flops_per_launch": alg,
             "executed_flops_per_launch": 2.0 * D * h1 * k_chunk * k_split, "avg_launch_us": round(t * 1e6, 2),
             "mfma": "v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate)"}
+
+
+def measure_tower_kernels(model, batches, bufs, masks_dev, B, L, steps=20):
+    """The two longest single launches of the step: the fused tower-pyramid forward (k_tower_fwd) and backward (k_tower_bwd).
+    Timed with the library's phase events on the launch stream (aread_debug_phase_times), one synchronised step per sample.
+    Both are chains of ~37 latency-bound phases with six segment-scoped BatchNorm hand-offs each: the honest roofline is how
+    far below the HBM rate the activation-sized traffic they touch is served.  Algorithmic bytes per sample (fp32, SURVEY 8d
+    widths 3x(64,32) / 6x(32,16) / 12x(16,8), experts 4x64): forward reads X 1024 + gate logits 432 and writes H + Act of six
+    layers 2 x 3456 + In 2304; backward reads H 3456 + X 1024 + Act of the level boundaries 768 and writes dH 3456 + dX 1024 +
+    gate-logit gradients 432."""
+    import ctypes as C
+    L.check(L.lib().aread_debug_set(b"phase_events", 1))
+    acc = [0.0, 0.0]
+    n = 0
+    try:
+        for i in range(steps + 3):
+            x, y = batches[i % len(batches)][:2]
+            model.train_step(x, y, bufs, masks_dev=masks_dev, set_grads=False)
+            torch.cuda.synchronize()
+            out = (C.c_float * 16)()
+            L.check(L.lib().aread_debug_phase_times(out, 16))
+            if i >= 3:
+                acc[0] += max(out[1], 0.0) * 1e3
+                acc[1] += max(out[4], 0.0) * 1e3
+                n += 1
+    finally:
+        L.check(L.lib().aread_debug_set(b"phase_events", 0))
+    fwd_us, bwd_us = acc[0] / n, acc[1] / n
+    fwd_bytes, bwd_bytes = (1024 + 432 + 2 * 3456 + 2304) * B, (3456 + 1024 + 768 + 3456 + 1024 + 432) * B
+    mk = lambda us, by, what: {"what": what, "bound": "latency (hbm reference)", "phase_us": round(us, 1),
+                               "achieved": round(by / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(by / us / 1e3 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": by}
+    return {"k_tower_fwd": mk(fwd_us, fwd_bytes, "MMoE mix + 3 tower levels + heads + bagging BCE, one launch (+ its counter memset)"),
+            "k_tower_bwd": mk(bwd_us, bwd_bytes, "heads + 3 tower levels + gate-mix + MMoE-mix backward, one launch (+ its counter memset)")}
 
 
 def measure_l2_kernel(model, bufs, L):

@@ -237,6 +237,17 @@ typedef struct aread_call {
                                  bit 1 (aread_forward): return with probs complete on `stream` but loss_out and the
                                  running statistics still finishing on the side stream (a following aread_backward
                                  queues behind them; aread_join covers both) */
+    /* Optional (aread_backward only): the embedding table's L2 pass (aread_l2_table_throttled + aread_l2_finish: grad =
+     * 2*coef*w written to l2_grad, coef*sum w^2 to l2_reg_out[0]) issued by the backward itself on an internal stream at
+     * the moment the latency-bound tower backward starts, so that its 356 MB of HBM traffic hides behind it instead of
+     * competing with the bandwidth-bound kernels around the forward/backward boundary.  Complete on `stream` when
+     * aread_backward returns (stream order).  l2_table == NULL: nothing is launched. */
+    const float* l2_table; int64_t l2_n; float l2_coef; int32_t l2_workgroups;
+    float* l2_grad; float* l2_partial; float* l2_reg_out;
+    /* Optional (aread_backward, only together with l2_table): the dense L2 terms (aread_l2_dense: grads += 2*coef*w,
+     * l2_reg_out[0] += sum coef*w^2) issued on the internal side stream right behind the last parameter-gradient
+     * reduction instead of by the caller after the join.  l2_dense_coef: device vector like params. */
+    const float* l2_dense_coef;
 } aread_call;
 
 /* e_in: embedding output in plan order [plan.max_rows][D] (aread_embed_fwd with the plan's row_sample). */

@@ -7,6 +7,6 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
            "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/pmc/p$i -- python $R/tools/pmc_kernels.py > $R/gpurun_out/pmc_p$i.log 2>&1 || echo "pass $i failed"
+  timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/pmc/p$i -- python $R/tools/pmc_kernels.py > $R/gpurun_out/pmc_p$i.log 2>&1 || echo "pass $i failed"
 done
 ls -R $R/gpurun_out/pmc | head -30
