@@ -1,6 +1,6 @@
 """Are tiny BatchNorm segments (2-3 rows) handled correctly?  HIP fp32 vs oracle fp32 vs oracle fp64."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import aread_amd
 from oracle import aread_oracle as O

@@ -2,7 +2,7 @@
 'domain_mask_bagging', domain_i=d), per-head BCELoss, get_regularization_loss, loss.backward(), torch Adam -- on a
 single-domain batch of 8192 Amazon-like samples, plus the eval path of Run.test."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import aread_oracle as O
 from tools import synth

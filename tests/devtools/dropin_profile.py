@@ -1,6 +1,6 @@
 """cProfile of the drop-in training step (host side)."""
 import sys, os, time, cProfile, pstats
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import aread_oracle as O
 from tools import synth

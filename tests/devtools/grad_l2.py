@@ -1,7 +1,7 @@
 """Per-tensor relative L2 error of the gradients: (a) golden multi-domain step (reference fixtures), (b) BASELINE-size
 proportional batch restricted to domains with >= 8 rows, against an fp64 run of the oracle.  Both GEMM precisions."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import aread_amd
 from oracle import aread_oracle as O

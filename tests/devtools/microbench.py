@@ -1,6 +1,6 @@
 """Per-kernel timing of the pieces of the path (development aid; bench.py is the judged benchmark)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 import aread_amd

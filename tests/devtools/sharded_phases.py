@@ -2,7 +2,7 @@
 import os, sys, time
 import numpy as np
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import aread_oracle as O
 from tools import synth
 from tests.util import build_model

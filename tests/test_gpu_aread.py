@@ -399,7 +399,7 @@ def test_baseline_size_step_vs_oracle_both_precisions(domain_dist):
     With domains drawn proportionally to config.py:60-61, a B=8192 batch contains domains of 1-3 rows.  BatchNorm
     over 2-3 rows is ill-conditioned in ANY fp32 implementation (x_hat = +-1 for two rows; rstd up to 1/sqrt(eps)
     per layer): the fp32 oracle itself differs from an fp64 oracle by 100 % on those gradients
-    (tools/debug_small_segments.py).  Logits are therefore asserted on domains with >= 8 rows (> 99 % of the
+    (tests/devtools/debug_small_segments.py).  Logits are therefore asserted on domains with >= 8 rows (> 99 % of the
     samples) and gradients on the uniform batch."""
     import aread_amd
     from tools import synth

@@ -158,7 +158,7 @@ def test_fused_training_step_matches_train_step_plus_torch_adam():
     assert float(dd.mean()) <= 2e-7
     # ... and the few hot-row entries above feed back into the next forward: isolated dense entries with near-zero
     # gradients then differ by a fraction of one lr step too (both paths are bit-reproducible run to run,
-    # tools/debug_fused_adam.py); everything else agrees to 5e-5 of ~3e-3 of movement
+    # tests/devtools/debug_fused_adam.py); everything else agrees to 5e-5 of ~3e-3 of movement
     assert int((dd > 5e-5).sum()) <= dd.numel() // 2000 and float(dd.max()) <= 2 * HYPER["lr"] * len(batches)
     # tensors the masks never reach keep their initial values and zero optimizer state in both
     present = fused._present_for(b.domain_mask)

@@ -22,5 +22,5 @@ for rows, cols in [(9728, 1024), (9728, 288), (9728, 512), (9728 * 4, 1024)]:
     tf = t(lambda: x.fill_(1.0))
     tc = t(lambda: y.copy_(x))
     tr = t(lambda: x.sum())
-    print(f"{rows}x{cols} fp32 ({mb:.1f} MB): fill {tf:6.2f} us ({mb / tf:.0f} GB/s)  copy {tc:6.2f} us ({2 * mb / tc:.0f} GB/s)  "
-          f"sum {tr:6.2f} us ({mb / tr:.0f} GB/s read)")
+    print(f"{rows}x{cols} fp32 ({mb:.1f} MB): fill {tf:6.2f} us ({mb / tf:.2f} TB/s)  copy {tc:6.2f} us ({2 * mb / tc:.2f} TB/s)  "
+          f"sum {tr:6.2f} us ({mb / tr:.2f} TB/s read)")

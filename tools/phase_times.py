@@ -31,8 +31,8 @@ for i in range(N + 5):
     if i >= 5:
         acc += np.maximum(np.array(out[:10]), 0) * 1e3
         tot.append(ev[0].elapsed_time(ev[1]) * 1e3)
-names = ["experts fwd", "mix0+towers+heads fwd", "(fwd tail -> bwd start)", "memset+heads bwd+dcn", "towers bwd", "dq fork + mix0 bwd", "gate wgrads issue",
-         "experts bwd", "-", "-"]
+names = ["experts fwd", "MMoE mix + towers + heads fwd", "(fwd tail -> bwd start)", "grads memset + dcn GEMM", "heads + towers + mixes bwd",
+         "side batch A fork (gate GEMMs)", "experts bwd", "-", "-", "-"]
 print(f"step (event to event, synced each step): {np.mean(tot):.1f} us")
 for n, v in zip(names, acc / N):
     print(f"  {n:28s} {v:8.1f} us")
