@@ -646,6 +646,7 @@ static int flush_reductions(Ctx& x) {
 }
 
 // one MLP layer backward.  d = dL/dAct on entry (in lw.dAct); on exit it holds dL/dH.
+static int g_fused_act_bn = -1;
 static int layer_bwd(Ctx& x, const LayerL& L, const LayerWs& lw, const float* in, float* d_in, int accumulate_d_in,
                      float* grads, int level, int64_t slab_off) {
     float* ws = x.ws;
@@ -655,11 +656,26 @@ static int layer_bwd(Ctx& x, const LayerL& L, const LayerWs& lw, const float* in
     a.gamma = x.params + L.gamma; a.beta = x.params + L.beta; a.bpart = ws + lw.bpart;
     a.ncols = L.ncols; a.h = L.out_dim; a.level = level; a.stack = L.stack; a.layer = L.layer; a.train = x.c->train;
     a.seed = x.c->drop_seed; a.thr = x.thr; a.keep_scale = x.keep_scale; a.r = x.r; a.mp = x.mp;
+    // wide layers: both passes in one launch with the segment sums handed off inside the kernel (k_act_bn_bwd); the
+    // workgroups that wait for each other sit next to each other in dispatch order, 2 x n_tiles resident ones suffice
+    // MEASURED SLOWER in the step (+40 us: 2432 workgroups that each stall ~5 us in the hand-off against two pure streaming
+    // passes): off by default, kept for A/B (AREAD_FUSED_ACT_BN=1 / aread_debug_set("fused_act_bn", 1)) and covered by a test
+    int& fused_ab = g_fused_act_bn;
+    if (fused_ab < 0) { const char* e = getenv("AREAD_FUSED_ACT_BN"); fused_ab = e ? atoi(e) : 0; }
+    const int n_chunks = cdiv(L.ncols, 64);
+    if (fused_ab && x.w.ab_sync >= 0 && x.w.tf_sync >= 0 && level < 0 && n_chunks <= 16 && L.layer < AREAD_MAX_LAYER && x.n_tiles <= 700) {
+        ActBnBwdP q = {};
+        q.a = a; q.cpart = ws + lw.cpart;
+        q.cnt = (unsigned*)(ws + x.w.ab_sync) + (size_t)L.layer * 16 * MAX_SEG;
+        q.err = (unsigned*)(ws + x.w.tf_sync) + AREAD_MAX_LEVEL * AREAD_MAX_LAYER * MAX_SEG;
+        LAUNCH(k_act_bn_bwd, dim3(x.n_tiles, n_chunks), dim3(256), q);
+    } else {
     LAUNCH(k_act_bwd, dim3(x.n_tiles, cdiv(L.ncols, 64)), dim3(256), a);
     BnBwdApplyP b = {};
     b.d = d; b.H = ws + lw.H; b.mean = ws + lw.mean; b.rstd = ws + lw.rstd; b.gamma = x.params + L.gamma; b.bpart = ws + lw.bpart;
     b.cpart = ws + lw.cpart; b.ncols = L.ncols; b.h = L.out_dim; b.level = level; b.train = x.c->train; b.r = x.r; b.mp = x.mp;
     LAUNCH(k_bn_bwd_apply, dim3(x.n_tiles, cdiv(L.ncols, 64)), dim3(256), b);
+    }
     AR_CHECK_ARG(x.bias.n < MAX_BN_LAYERS_DECL, "too many layers");
     BiasOne& bo = x.bias.d[x.bias.n++];
     bo.cpart = ws + lw.cpart; bo.bpart = ws + lw.bpart; bo.db = grads + L.b; bo.dgamma = grads + L.gamma; bo.dbeta = grads + L.beta;
@@ -718,6 +734,7 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     const float* P = x.params;
     phase_mark(x.st, 3);
     AR_HIP(hipMemsetAsync(grads, 0, (size_t)m->n_params * sizeof(float), x.st));
+    if (x.w.ab_sync >= 0) AR_HIP(hipMemsetAsync(ws + x.w.ab_sync, 0, (size_t)AREAD_MAX_LAYER * 16 * MAX_SEG * sizeof(unsigned), x.st));
     // 1. dz
     HeadsP hp = {};
     hp.prob = ws + x.w.prob; hp.dz = ws + x.w.dz; hp.n_heads = m->n_heads; hp.ld_h = m->ld_h; hp.B = c->B;
@@ -902,6 +919,7 @@ extern "C" int aread_debug_set(const char* key, int value) {
     AR_CHECK_ARG(key != nullptr, "aread_debug_set: null key");
     if (!strcmp(key, "fused_towers")) g_fused_mode = value;
     else if (!strcmp(key, "fused_towers_bwd")) g_fused_bwd = value;
+    else if (!strcmp(key, "fused_act_bn")) g_fused_act_bn = value;
     else if (!strcmp(key, "wide_gemm")) g_wide_mode = value;
     else if (!strcmp(key, "tf_stamps")) g_tf_stamps = value;
     else if (!strcmp(key, "phase_events")) g_phase_on = value;

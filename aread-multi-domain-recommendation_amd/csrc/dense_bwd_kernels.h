@@ -409,6 +409,166 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const BnBwdApplyP p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_act_bwd + k_bn_bwd_apply in ONE launch for the wide (expert) layers: the dropout / ReLU backward keeps dyhat and xhat of
+// its 64x64 block in registers, hands the block's column sums to the other tiles of the segment inside the kernel (the
+// protocol of tower_fused.h: write-through partial stores into bpart, drain, barrier, one agent-scope counter add, bounded
+// relaxed poll), merges the segment's partials in the order of k_bn_bwd_apply and applies the BatchNorm backward from the
+// registers: d and H are read once instead of twice and one launch boundary disappears (expert L1: 28 + 35 us -> see DESIGN).
+// Grid (tile, 64-column chunk): the workgroups that wait for each other differ only in the tile index and are dispatched
+// next to each other, so they are co-resident whenever the device holds 2 x n_tiles workgroups (checked by the launcher).
+// ------------------------------------------------------------------------------------------------
+struct ActBnBwdP {
+    ActBwdP a;                          // d, H, mean, rstd, gamma, beta, bpart, dropout site ...
+    float* cpart;                       // [n_tiles][ncols]
+    unsigned* cnt;                      // [n_chunks][MAX_SEG] arrival counters, zeroed before the launch
+    unsigned* err;
+};
+
+__device__ __forceinline__ void ab_store_sc1(float* p, float a, float b) {
+    union { float f[2]; unsigned long long u; } v;
+    v.f[0] = a; v.f[1] = b;
+    __hip_atomic_store((unsigned long long*)p, v.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ab_load_sc1(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(256) void k_act_bn_bwd(const ActBnBwdP q) {
+    const ActBwdP& p = q.a;
+    __shared__ float s1[16][64], s2[16][64];
+    __shared__ float s_half[2][128];
+    __shared__ float s_sum[128];
+    const int tile = blockIdx.x, c0 = blockIdx.y * 64;
+    const int seg = p.r.tile_seg[tile];
+    if (seg < 0) return;
+    const int nvalid = p.r.tile_valid[tile];
+    const int rg = threadIdx.x >> 4, cq = threadIdx.x & 15;
+    const int c = c0 + cq * 4;
+    const bool col_ok = c < p.ncols;
+    const int g = col_ok ? c / p.h : 0;
+    bool act = col_ok;
+    if (act && p.level >= 0) act = active_level(p.mp, p.level)[seg * MAX_TOWER + g] != 0;
+    const int cnt = p.r.seg_count[seg];
+    const bool bn = cnt > 1;
+    const bool sync_stats = p.train && bn;
+    float mu[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {1.f, 1.f, 1.f, 1.f}, ga[4] = {1.f, 1.f, 1.f, 1.f}, be[4] = {0.f, 0.f, 0.f, 0.f};
+    if (col_ok) {
+        const int64_t so = (int64_t)seg * p.ncols + c;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { mu[i] = p.mean[so + i]; rs[i] = p.rstd[so + i]; ga[i] = p.gamma[c + i]; be[i] = p.beta[c + i]; }
+    }
+    const uint32_t site = (uint32_t)((p.stack * 8 + p.layer) * 64 + g);
+    const int cg = c - g * p.h;
+    // ---- 1. dropout / ReLU backward: dyhat, xhat of this thread's four rows stay in registers --------------------------
+    float dy[4][4], xh[4][4];
+    float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 dv[4], hv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int rr = rg + 16 * k;
+        const int64_t row = (int64_t)tile * TILE_M + rr;
+        dv[k] = make_float4(0.f, 0.f, 0.f, 0.f); hv[k] = dv[k];
+        if (act && rr < nvalid) { dv[k] = *(const float4*)(p.d + row * p.ncols + c); hv[k] = *(const float4*)(p.H + row * p.ncols + c); }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int rr = rg + 16 * k;
+        const int64_t row = (int64_t)tile * TILE_M + rr;
+        const float d[4] = {dv[k].x, dv[k].y, dv[k].z, dv[k].w}, hh[4] = {hv[k].x, hv[k].y, hv[k].z, hv[k].w};
+        const bool on = act && rr < nvalid;
+        const uint32_t key = (on && p.train && p.thr) ? drop_row_key(p.seed, (uint32_t)p.r.row_sample[row]) : 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float x = 0.f, v = 0.f;
+            if (on) {
+                x = (hh[i] - mu[i]) * rs[i];
+                const float y = bn ? x * ga[i] + be[i] : hh[i];
+                v = d[i];
+                if (p.train && p.thr) v = drop_keep(key, site, (uint32_t)(cg + i), p.thr) ? v * p.keep_scale : 0.f;
+                v = y > 0.f ? v : 0.f;
+                a1[i] += v;
+                a2[i] += v * x;
+            }
+            dy[k][i] = v; xh[k][i] = x;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s1[rg][cq * 4 + i] = a1[i]; s2[rg][cq * 4 + i] = a2[i]; }
+    __syncthreads();
+    if (threadIdx.x < 64 && c0 + threadIdx.x < p.ncols) {
+        float t1 = 0.f, t2 = 0.f;
+        for (int k = 0; k < 16; ++k) { t1 += s1[k][threadIdx.x]; t2 += s2[k][threadIdx.x]; }
+        ab_store_sc1(p.bpart + ((int64_t)tile * p.ncols + c0 + threadIdx.x) * 2, t1, t2);
+    }
+    // ---- 2. hand-off: every tile of the segment has published this chunk's partials ----------------------------------
+    const int ncol_here = (p.ncols - c0 < 64 ? p.ncols - c0 : 64) * 2;
+    if (sync_stats) {
+        const int t0 = p.r.seg_start[seg] / TILE_M, nt = (cnt + TILE_M - 1) / TILE_M;
+        unsigned* ctr = q.cnt + (size_t)blockIdx.y * MAX_SEG + seg;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nt) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 22)) { __hip_atomic_store(q.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+        }
+        __syncthreads();
+        // per-segment sums of this block's 64 columns, the order of k_bn_bwd_apply: two interleaved halves, then combined
+        const int v = threadIdx.x & 127, half = threadIdx.x >> 7;
+        float acc = 0.f;
+        if (v < ncol_here) {
+            const float* src = p.bpart + ((int64_t)t0 * p.ncols + c0) * 2 + v;
+            float b[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) { const int t = half + 2 * k; b[k] = t < nt ? ab_load_sc1(src + (int64_t)t * p.ncols * 2) : 0.f; }
+#pragma unroll
+            for (int k = 0; k < 12; ++k) acc += b[k];
+            for (int t = half + 24; t < nt; t += 2) acc += ab_load_sc1(src + (int64_t)t * p.ncols * 2);
+        }
+        s_half[half][v] = acc;
+        __syncthreads();
+        if (threadIdx.x < 128) s_sum[threadIdx.x] = s_half[0][threadIdx.x] + s_half[1][threadIdx.x];
+        __syncthreads();
+    }
+    // ---- 3. BatchNorm backward from the registers: dH = gamma*rstd*(dyhat - s1/n - xhat*s2/n); column sums -> cpart ----
+    const bool bna = bn && act;
+    const float inv_n = 1.0f / (float)cnt;
+    float m1[4] = {0.f, 0.f, 0.f, 0.f}, m2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (col_ok && sync_stats) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { m1[i] = s_sum[(cq * 4 + i) * 2] * inv_n; m2[i] = s_sum[(cq * 4 + i) * 2 + 1] * inv_n; }
+    }
+    float a3[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int rr = rg + 16 * k;
+        if (!col_ok) break;
+        const int64_t row = (int64_t)tile * TILE_M + rr;
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v = dy[k][i];
+            if (bna && rr < nvalid) v = ga[i] * rs[i] * (v - m1[i] - xh[k][i] * m2[i]);
+            o[i] = v;
+            a3[i] += rr < nvalid ? v : 0.f;
+        }
+        *(float4*)(p.d + row * p.ncols + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s1[rg][cq * 4 + i] = a3[i];
+    __syncthreads();
+    if (threadIdx.x < 64 && c0 + threadIdx.x < p.ncols) {
+        float t1 = 0.f;
+        for (int k = 0; k < 16; ++k) t1 += s1[k][threadIdx.x];
+        q.cpart[(int64_t)tile * p.ncols + c0 + threadIdx.x] = t1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // gate-mix backward, level l >= 1: dIn[row][t][:] -> dprev[row][s][:] and dglogT
 // ------------------------------------------------------------------------------------------------
 struct MixLBwdP {

@@ -283,6 +283,7 @@ void ws_layout(const aread_model* m, int64_t B, int n_seg, WsLayout* w) {
     w->rw_part = take(&o, tiles * 4 * ((int64_t)(2 * MAX_CROSS + 1) * D + 4));
     w->misc_part = take(&o, tiles * 4 * 1024);
     w->tf_sync = take(&o, 2 * (AREAD_MAX_LEVEL * AREAD_MAX_LAYER * MAX_SEG + 64));
+    w->ab_sync = take(&o, AREAD_MAX_LAYER * 16 * MAX_SEG);      // arrival counters of k_act_bn_bwd: [layer][<= 16 column chunks][segment]
     w->total = o;
 }
 
@@ -380,6 +381,7 @@ void mlp_ws_layout(const aread_model* m, int64_t B, WsLayout* w) {
     const int64_t rows = plan_max_rows(B, 1), tiles = rows / TILE_M;
     int64_t o = 0;
     memset(w, 0, sizeof(*w));
+    w->ab_sync = -1; w->tf_sync = -1;                // no fused hand-off kernels in the stand-alone MLP
     w->max_rows = rows; w->n_tiles = tiles;
     w->In[0] = take(&o, rows * m->mlp_in);           // padded copy of x
     w->dIn[0] = take(&o, rows * m->mlp_in);          // padded dx

@@ -70,6 +70,7 @@ struct WsLayout {                            // float offsets into the workspace
     int64_t kact, seg_dom;                   // ints: active heads per seg, domain of each seg
     int64_t loss_part, gate_part, rw_part, misc_part;
     int64_t tf_sync;                         // fused tower kernels: arrival counters [MAX_LEVEL*MAX_LAYER][MAX_SEG] x 2 (fwd, bwd) + error words
+    int64_t ab_sync = -1;         // k_act_bn_bwd arrival counters (-1: layout without them, e.g. the stand-alone MLP)
     int64_t slab_ex[AREAD_MAX_LAYER], slab_tw[AREAD_MAX_LEVEL][AREAD_MAX_LAYER], slab_head, slab_gate, slab_tgate;
     int64_t total;                           // floats
 };

@@ -104,6 +104,38 @@ def test_fused_tower_backward_matches_layerwise(dropout, B, p_active):
         assert d <= 2e-4 * np.abs(a[k]).max() + 1e-12, (k, d)
 
 
+def test_fused_act_bn_backward_matches_two_pass():
+    """k_act_bn_bwd (dropout/ReLU backward + BatchNorm backward of an expert layer in one launch, segment sums handed off in the
+    kernel; off by default: measured slower) against the two-kernel sequence: identical gradients up to summation order."""
+    import aread_amd
+    from aread_amd import _lib as L
+    spec = spec_full(dropout=0.2)
+    rng = np.random.default_rng(31)
+    x, y = _batch(spec, rng, 2500)
+    masks = [O.random_valid_mask(spec, rng, 0.6) for _ in range(spec.n_domain)]
+    model, P = build_model(spec, 77, precision="bf16x3")
+    model.train()
+    model._stats0 = model.bn_stats.clone()
+    model.domain_mask = [[torch.tensor(np.asarray(m), dtype=torch.bool, device="cuda") for m in mk] for mk in masks]
+    md = aread_amd.pack_masks(masks, spec.n_domain, model.edge_num, "cuda")
+    names = [("ex0.dAct", 4 * 256), ("ex2.dAct", 4 * 64)]
+    res = []
+    try:
+        for v in (0, 1):
+            L.check(L.lib().aread_debug_set(b"fused_act_bn", v))
+            res.append(_run(model, x, y, md, 1, names))
+    finally:
+        L.check(L.lib().aread_debug_set(b"fused_act_bn", 0))
+    a, b = res
+    assert b["err"] == 0
+    for n, _ in names:
+        ref, got = a[n][:a["rows"]], b[n][:a["rows"]]
+        np.testing.assert_allclose(got, ref, rtol=2e-4, atol=1e-5 * np.abs(ref).max(), err_msg=n)
+    for k in ("gdense", "gtable"):
+        d = np.abs(b[k] - a[k]).max()
+        assert d <= 1e-4 * np.abs(a[k]).max() + 1e-12, (k, d)
+
+
 def test_fused_towers_eval_and_wo_mask_forward():
     """eval mode (running statistics, no hand-off) and the unmasked warm-up mode through the drop-in forward()."""
     from aread_amd import _lib as L
