@@ -66,6 +66,8 @@ for _n, _r, _a in [
     ("aread_join", C.c_int, [C.c_void_p, C.c_void_p]),
     ("aread_debug_ws_offset", C.c_int64, [C.c_void_p, C.c_int64, C.c_int, C.c_char_p]),
     ("aread_l2_dense", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    ("aread_l2_dense_total", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_void_p]),
 ]:
     L.register(_n, _r, _a)
 
@@ -708,8 +710,15 @@ class AREAD(HempMixin, nn.Module):
         # segmented reduction into the table gradient, then the join with the library's parameter-gradient reductions
         # (long finished by then) and the dense L2 term
         self.embedding.reduce_sorted(x, bufs["de"], bufs["gtable"])
-        self.step_finish(bufs)
-        torch.add(bufs["loss"][:1], bufs["reg"][:1], out=bufs["total"])
+        if self._pending_dense_l2:      # join + dense L2 terms + total = loss + reg in one launch
+            L.check(L.lib().aread_join(self._handle, L.stream()))
+            L.check(L.lib().aread_l2_dense_total(L.ptr(self.dense), L.ptr(self._l2_coef(self.dense.device)), self.dense.numel(),
+                                                 L.ptr(bufs["gdense"]), L.ptr(bufs["reg"]), 1, L.ptr(bufs["loss"]),
+                                                 L.ptr(bufs["total"]), L.stream()))
+            self._pending_dense_l2 = False
+        else:
+            self.step_finish(bufs)
+            torch.add(bufs["loss"][:1], bufs["reg"][:1], out=bufs["total"])
         if set_grads:
             for p in self.dense_params:
                 p.grad = None

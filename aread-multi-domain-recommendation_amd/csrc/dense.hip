@@ -733,8 +733,10 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     float* ws = x.ws;
     const float* P = x.params;
     phase_mark(x.st, 3);
+    if (g_fused_act_bn < 0) { const char* e = getenv("AREAD_FUSED_ACT_BN"); g_fused_act_bn = e ? atoi(e) : 0; }
     AR_HIP(hipMemsetAsync(grads, 0, (size_t)m->n_params * sizeof(float), x.st));
-    if (x.w.ab_sync >= 0) AR_HIP(hipMemsetAsync(ws + x.w.ab_sync, 0, (size_t)AREAD_MAX_LAYER * 16 * MAX_SEG * sizeof(unsigned), x.st));
+    if (x.w.ab_sync >= 0 && g_fused_act_bn > 0)
+        AR_HIP(hipMemsetAsync(ws + x.w.ab_sync, 0, (size_t)AREAD_MAX_LAYER * 16 * MAX_SEG * sizeof(unsigned), x.st));
     // 1. dz
     HeadsP hp = {};
     hp.prob = ws + x.w.prob; hp.dz = ws + x.w.dz; hp.n_heads = m->n_heads; hp.ld_h = m->ld_h; hp.B = c->B;
@@ -1051,11 +1053,16 @@ extern "C" int aread_mlp_backward(const aread_model* m, const aread_mlp_call* c,
     return AREAD_OK;
 }
 
+extern "C" int aread_l2_dense_total(const float* params, const float* coef, int64_t n, float* grads, float* loss_out,
+                                    int accumulate, const float* loss_in, float* total_out, void* stream) {
+    AR_CHECK_ARG(params && coef && loss_out && n > 0, "aread_l2_dense: bad arguments");
+    // the block partials live at the tail of loss_out's caller-provided scratch: loss_out[1..256]; the last block finishes
+    hipLaunchKernelGGL(k_l2_dense, dim3(256), dim3(256), 0, (hipStream_t)stream, params, coef, n, grads, loss_out + 1, loss_out,
+                       accumulate, loss_in, total_out);
+    AR_LAUNCH_CHECK();
+    return AREAD_OK;
+}
 extern "C" int aread_l2_dense(const float* params, const float* coef, int64_t n, float* grads, float* loss_out,
                               int accumulate, void* stream) {
-    AR_CHECK_ARG(params && coef && loss_out && n > 0, "aread_l2_dense: bad arguments");
-    // the partial sums live at the tail of loss_out's caller-provided scratch: loss_out[1..256]
-    hipLaunchKernelGGL(k_l2_dense, dim3(256), dim3(256), 0, (hipStream_t)stream, params, coef, n, grads, loss_out + 1);
-    AR_LAUNCH_CHECK();
-    return aread_l2_finish(loss_out + 1, 256, 1.0f, loss_out, accumulate, stream);
+    return aread_l2_dense_total(params, coef, n, grads, loss_out, accumulate, nullptr, nullptr, stream);
 }

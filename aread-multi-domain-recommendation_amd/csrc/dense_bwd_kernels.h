@@ -1019,16 +1019,50 @@ __global__ __launch_bounds__(256) void k_bn_running(const BnRunAllP a) {
 }
 
 // dense L2: partial sums of coef*w^2 and grads += 2*coef*w
-__global__ __launch_bounds__(256) void k_l2_dense(const float* w, const float* coef, int64_t n, float* grads, float* partial) {
+// One launch: block partials of sum coef*w^2 (float4 lanes), grads += 2*coef*w, and the LAST block to finish (self-resetting
+// ticket counter) adds the 256 partials in index order into loss_out[0] and, when asked, forms total = loss_in + loss_out[0]
+// (the step's final scalar) -- what used to be k_l2_dense + k_l2_finish + a torch.add at the serial tail of the step.
+__device__ unsigned g_l2_dense_ticket = 0;
+__global__ __launch_bounds__(256) void k_l2_dense(const float* w, const float* coef, int64_t n, float* grads, float* partial,
+                                                  float* loss_out, int accumulate, const float* loss_in, float* total_out) {
     float acc = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t n4 = ((((uintptr_t)w | (uintptr_t)coef | (uintptr_t)grads) & 15) == 0) ? n >> 2 : 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 c = ((const float4*)coef)[i], v = ((const float4*)w)[i];
+        acc += c.x * v.x * v.x; acc += c.y * v.y * v.y; acc += c.z * v.z * v.z; acc += c.w * v.w * v.w;
+        if (grads && (c.x != 0.f || c.y != 0.f || c.z != 0.f || c.w != 0.f)) {
+            float4 g = ((float4*)grads)[i];
+            g.x += 2.0f * c.x * v.x; g.y += 2.0f * c.y * v.y; g.z += 2.0f * c.z * v.z; g.w += 2.0f * c.w * v.w;
+            ((float4*)grads)[i] = g;
+        }
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float c = coef[i], v = w[i];
         acc += c * v * v;
         if (grads && c != 0.f) grads[i] += 2.0f * c * v;
     }
     acc = wave_sum(acc);
     __shared__ float s[4];
+    __shared__ bool s_last;
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) partial[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(partial + blockIdx.x, (s[0] + s[1]) + (s[2] + s[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        s_last = atomicInc(&g_l2_dense_ticket, gridDim.x - 1) == gridDim.x - 1;       // wraps to 0: ready for the next launch
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    float v = threadIdx.x < gridDim.x ? __hip_atomic_load(partial + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+    __shared__ float s_p[256];
+    s_p[threadIdx.x] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = 0.f;
+        for (int k = 0; k < (int)gridDim.x && k < 256; ++k) tot += s_p[k];
+        const float r = accumulate ? loss_out[0] + tot : tot;
+        loss_out[0] = r;
+        if (total_out) total_out[0] = (loss_in ? loss_in[0] : 0.f) + r;
+    }
 }

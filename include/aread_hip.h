@@ -306,6 +306,10 @@ int aread_model_l2_coef(const aread_model* m, float* coef_host);
 int64_t aread_debug_ws_offset(const aread_model* m, int64_t B, int n_seg, const char* name);
 int aread_l2_dense(const float* params, const float* coef, int64_t n, float* grads, float* loss_out,
                    int accumulate, void* stream);
+/* The same in one launch with the step's final scalar: total_out[0] = loss_in[0] + loss_out[0] (both optional).  The last
+ * block to finish does the fixed-order sum of the block partials (a process-wide self-resetting ticket: one call at a time). */
+int aread_l2_dense_total(const float* params, const float* coef, int64_t n, float* grads, float* loss_out,
+                         int accumulate, const float* loss_in, float* total_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Wide split-bf16 GEMM (csrc/gemm_wide.h): the kernel behind the expert / tower Linear layers of aread_forward /
