@@ -480,9 +480,16 @@ extern "C" int aread_forward(const aread_model* m, const aread_call* c, const fl
     mp.seg_dom = (int32_t*)(ws + x.w.seg_dom); mp.grp = ws + x.w.grp;
     const bool fused_towers = tower_fused_ok(x);
     if (cfg.precision == 1 && wide_any()) TRY(prepare_wimg(x, 0));    // forward weight images: the wide expert GEMMs need them first
+    // 4. experts FIRST on the main stream (issue order = the order a captured graph schedules independent branches): the
+    // side work below forks from the point before them
+    hipEvent_t ev_f0 = x.m->ev[x.ev_next++ % (x.m->n_ev - 1)];
+    AR_HIP(hipEventRecord(ev_f0, x.st));
+    phase_mark(x.st, 0);
+    TRY(stack_fwd(x, m->experts, x.w.ex, e_in, -1));
+    phase_mark(x.st, 1);
     // 1.-3. (side stream, joined before the MMoE mix: the expert layers need none of it) mask tables, row-wise trunk,
     // gate logits, cross-network part of the heads
-    TRY(fork_side(x));
+    AR_HIP(hipStreamWaitEvent(x.side, ev_f0, 0));
     {
         const hipStream_t main_st = x.st;
         x.st = x.side;
@@ -509,10 +516,6 @@ extern "C" int aread_forward(const aread_model* m, const aread_call* c, const fl
                         m->n_heads, D, 0, 1));
         x.st = main_st;
     }
-    phase_mark(x.st, 0);
-    // 4. experts
-    TRY(stack_fwd(x, m->experts, x.w.ex, e_in, -1));
-    phase_mark(x.st, 1);
     // 5.-7. MMoE mix, tower pyramid, heads + fused bagging loss: one launch when the configuration allows it
     TRY(join_side(x));
     const bool want_gates = c->gate_stats != nullptr && m->gate_rows > 0;
@@ -613,6 +616,13 @@ static int wgrad(Ctx& x, const float* dY, int64_t ld_dy, int64_t dy_gs, const fl
 
 // fork once, then every pending weight-gradient GEMM on the side stream.  split-bf16 mode: the row-contiguous operands go
 // through the transposing LDS reads (k_gemm_bf3_rc), 3 bf16 MFMA products instead of the fp32 MFMA.
+static int flush_wgrads_range(Ctx& x, int lo, int hi) {
+    for (int i = lo; i < hi; ++i) {
+        if (x.m->cfg.precision == 1) TRY(launch_gemm_bf3_rc(x.pend[i], x.side));
+        else TRY(launch_gemm(x.pend[i], false, false, x.side));
+    }
+    return AREAD_OK;
+}
 static int flush_wgrads(Ctx& x, bool fork) {
     if (fork) TRY(fork_side(x));
     for (int i = 0; i < x.n_pend; ++i) {
@@ -734,39 +744,41 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     const float* P = x.params;
     phase_mark(x.st, 3);
     if (g_fused_act_bn < 0) { const char* e = getenv("AREAD_FUSED_ACT_BN"); g_fused_act_bn = e ? atoi(e) : 0; }
-    AR_HIP(hipMemsetAsync(grads, 0, (size_t)m->n_params * sizeof(float), x.st));
-    if (x.w.ab_sync >= 0 && g_fused_act_bn > 0)
-        AR_HIP(hipMemsetAsync(ws + x.w.ab_sync, 0, (size_t)AREAD_MAX_LAYER * 16 * MAX_SEG * sizeof(unsigned), x.st));
+    // Issue order = the order in which a captured graph schedules independent branches (and the order a just-in-time host
+    // feeds the queues): the main stream's dependent chain is issued FIRST in every section, the side work behind it waits on
+    // events recorded at the right points of the main stream (mark_main / hipStreamWaitEvent).
+    auto mark_main = [&](hipEvent_t* ev) -> int {
+        *ev = x.m->ev[x.ev_next++ % (x.m->n_ev - 1)];
+        AR_HIP(hipEventRecord(*ev, x.st));
+        return AREAD_OK;
+    };
+    const hipStream_t main_st = x.st;
     // 1. dz
     HeadsP hp = {};
     hp.prob = ws + x.w.prob; hp.dz = ws + x.w.dz; hp.n_heads = m->n_heads; hp.ld_h = m->ld_h; hp.B = c->B;
     hp.y = c->y; hp.seg_weight = c->seg_weight; hp.dprobs = dprobs; hp.level = LL; hp.r = x.r; hp.mp = x.mp;
     if (dprobs || !c->y) LAUNCH(k_heads_dz, dim3(x.n_tiles * SUB), dim3(256), hp);   // else: fused into k_heads_fwd
+    hipEvent_t ev_b0;                                        // dz and the forward's results are final
+    TRY(mark_main(&ev_b0));
     const bool fused_bwd = c->train && tower_fused_bwd_ok(x);
     const int nle = m->experts.n_layers;
+    AR_CHECK_ARG(m->n_heads * m->h_last <= 1024, "aread_backward: n_heads*h_last too large");
     auto table_l2_pass = [&]() -> int {
         // the caller's embedding-table L2 sweep, released now: it runs beside the tower backward (a chain of latency-bound
         // phases that leaves the HBM idle) on the second side stream, which joins the main stream at the end of the call
         if (!c->l2_table) return AREAD_OK;
-        hipEvent_t ev = x.m->ev[x.ev_next++ % (x.m->n_ev - 1)];
-        AR_HIP(hipEventRecord(ev, x.st));
-        AR_HIP(hipStreamWaitEvent(m->side2, ev, 0));
+        AR_HIP(hipStreamWaitEvent(m->side2, ev_b0, 0));
         TRY(aread_l2_table_throttled(c->l2_table, c->l2_n, c->l2_coef, 1.0f, c->l2_grad, c->l2_partial, c->l2_workgroups, m->side2));
         TRY(aread_l2_finish(c->l2_partial, aread_l2_partials(), c->l2_coef, c->l2_reg_out, 0, m->side2));
         return AREAD_OK;
     };
+    // dV[:, :D] = dz^T cn: queued for the side stream
+    TRY(wgrad(x, ws + x.w.dz, m->ld_h, 0, ws + x.w.cn, D, 0, 1, m->n_heads, D, grads + m->head_w, m->head_ld, 0, nullptr, x.w.slab_head));
+    phase_mark(x.st, 4);
+    TRY(table_l2_pass());
     if (fused_bwd) {
-        // dcn = dz V[:, :D]   and (queued for the side stream)   dV[:, :D] = dz^T cn
-        TRY(simple_gemm(x, ws + x.w.dz, m->ld_h, true, P + m->head_w, m->head_ld, false, ws + x.w.dcn, D, nullptr, (int)x.rows, D,
-                        m->n_heads, 0, 1));
-        TRY(wgrad(x, ws + x.w.dz, m->ld_h, 0, ws + x.w.cn, D, 0, 1, m->n_heads, D, grads + m->head_w, m->head_ld, 0, nullptr, x.w.slab_head));
-        AR_CHECK_ARG(m->n_heads * m->h_last <= 1024, "aread_backward: n_heads*h_last too large");
-        phase_mark(x.st, 4);
         // 2.-4. heads backward, tower pyramid, gate-mix and MMoE-mix backward: one launch
-        TRY(table_l2_pass());
         TRY(tower_fused_bwd(x, grads));
-        phase_mark(x.st, 5);
-        if (m->gate_rows == 0) AR_HIP(hipMemsetAsync(ws + x.w.dq, 0, (size_t)x.rows * 2 * E * sizeof(float), x.st));
     } else {
     // 2. heads backward
     const LayerWs& last = x.w.tw[LL][m->towers[LL].n_layers - 1];
@@ -776,12 +788,6 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     hb.part = ws + x.w.misc_part; hb.ldp = 1024; hb.r = x.r;
     AR_CHECK_ARG(m->n_heads * m->h_last <= 1024, "aread_backward: n_heads*h_last too large");
     LAUNCH(k_heads_bwd, dim3(x.n_tiles * SUB), dim3(256), hb);
-    // dcn = dz V[:, :D]   and (queued for the side stream)   dV[:, :D] = dz^T cn
-    TRY(simple_gemm(x, ws + x.w.dz, m->ld_h, true, P + m->head_w, m->head_ld, false, ws + x.w.dcn, D, nullptr, (int)x.rows, D,
-                    m->n_heads, 0, 1));
-    TRY(wgrad(x, ws + x.w.dz, m->ld_h, 0, ws + x.w.cn, D, 0, 1, m->n_heads, D, grads + m->head_w, m->head_ld, 0, nullptr, x.w.slab_head));
-    phase_mark(x.st, 4);
-    TRY(table_l2_pass());
     // 3. tower pyramid, top down (the weight gradients queue up)
     for (int l = LL; l >= 0; --l) {
         const StackL& S = m->towers[l];
@@ -801,8 +807,6 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
             LAUNCH(k_mixl_bwd, dim3(x.n_tiles * SUB), dim3(256), mb);
         }
     }
-    phase_mark(x.st, 5);
-    if (m->gate_rows == 0) AR_HIP(hipMemsetAsync(ws + x.w.dq, 0, (size_t)x.rows * 2 * E * sizeof(float), x.st));
     // 4. MMoE mix backward
     const LayerL& EL = m->experts.L[nle - 1];
     Mix0BwdP m0 = {};
@@ -811,16 +815,35 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     m0.r = x.r; m0.mp = x.mp;
     LAUNCH(k_mix0_bwd, dim3(x.n_tiles * SUB), dim3(256), m0);
     }
-    // ---- side batch A (ONE fork): everything off the critical path that the tower / gate backward has made ready -------------
+    phase_mark(x.st, 5);
+    // gate weight gradients (queued), then the mark the side stream's first batch waits for
     const int n_ge = cfg.n_tower[0] * cfg.n_expert;
-    const hipStream_t main_st = x.st;
     AR_CHECK_ARG(m->gate_rows <= 1024 && n_ge <= 1024, "aread_backward: too many gate rows");
     TRY(wgrad(x, ws + x.w.dglogE, m->ld_ge, 0, e_in, D, 0, 1, n_ge, D, grads + m->gate_w, D, 0, nullptr, x.w.slab_gate));
     if (m->gate_rows > 0)
         TRY(wgrad(x, ws + x.w.dglogT, m->ld_gt, 0, ws + x.w.q, 2 * E, 0, 1, m->gate_rows, 2 * E, grads + m->tgate_w, 2 * E, 0, nullptr,
                   x.w.slab_tgate));
-    TRY(fork_side(x));
+    const int n_pend_a = x.n_pend;                           // weight gradients whose operands are final at ev_b1
+    hipEvent_t ev_b1;
+    TRY(mark_main(&ev_b1));
+    phase_mark(x.st, 6);
+    // 5a. experts, all layers but the first: main stream, issued before any side work
+    for (int j = nle - 1; j >= 1; --j)
+        TRY(layer_bwd(x, m->experts.L[j], x.w.ex[j], ws + x.w.ex[j - 1].Act, ws + x.w.ex[j - 1].dAct, 0, grads, -1, x.w.slab_ex[j]));
+    hipEvent_t ev_b2;                                        // dH of those layers is final
+    TRY(mark_main(&ev_b2));
+    // ---- side stream: gradient buffer initialisation + dcn (need only dz), then batch A behind the tower backward, then the
+    // deeper expert layers' weight gradients and the reductions of everything so far (batch B) ----------------------------
     x.st = x.side;
+    AR_HIP(hipStreamWaitEvent(x.side, ev_b0, 0));
+    AR_HIP(hipMemsetAsync(grads, 0, (size_t)m->n_params * sizeof(float), x.st));
+    if (x.w.ab_sync >= 0 && g_fused_act_bn > 0)
+        AR_HIP(hipMemsetAsync(ws + x.w.ab_sync, 0, (size_t)AREAD_MAX_LAYER * 16 * MAX_SEG * sizeof(unsigned), x.st));
+    // dcn = dz V[:, :D]
+    TRY(simple_gemm(x, ws + x.w.dz, m->ld_h, true, P + m->head_w, m->head_ld, false, ws + x.w.dcn, D, nullptr, (int)x.rows, D,
+                    m->n_heads, 0, 1));
+    AR_HIP(hipStreamWaitEvent(x.side, ev_b1, 0));
+    if (m->gate_rows == 0) AR_HIP(hipMemsetAsync(ws + x.w.dq, 0, (size_t)x.rows * 2 * E * sizeof(float), x.st));
     // gate-input gradients first: dq = dglogT Tw (tower gates) and deg = dglogE Gw (MMoE gates) feed the row-wise backward
     if (m->gate_rows > 0)
         TRY(simple_gemm(x, ws + x.w.dglogT, m->ld_gt, true, P + m->tgate_w, 2 * E, false, ws + x.w.dq, 2 * E, nullptr, (int)x.rows,
@@ -829,7 +852,7 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
                     n_ge, 0, 1));
     hipEvent_t ev_gates = x.m->ev[x.ev_next++ % (x.m->n_ev - 1)];
     AR_HIP(hipEventRecord(ev_gates, x.side));
-    // head tails (partials of k_heads_bwd), gate biases: all through misc_part, in this order on this one stream
+    // head tails (partials of the heads backward), gate biases: all through misc_part, in this order on this one stream
     LAUNCH(k_reduce_tiles, dim3(cdiv(m->n_heads * m->h_last, 32)), dim3(256), ws + x.w.misc_part, (int64_t)1024, m->n_heads * m->h_last,
            grads + m->head_w + D, m->h_last, (int64_t)m->head_ld, 0, SUB, x.r);
     LAUNCH(k_colsum, dim3(x.n_tiles), dim3(256), ws + x.w.dglogE, (int64_t)m->ld_ge, n_ge, ws + x.w.misc_part, (int64_t)1024, x.r);
@@ -841,10 +864,14 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
         LAUNCH(k_reduce_tiles, dim3(cdiv(m->gate_rows, 32)), dim3(256), ws + x.w.misc_part, (int64_t)1024, m->gate_rows,
                grads + m->tgate_b, m->gate_rows, (int64_t)0, 0, 1, x.r);
     }
+    TRY(flush_wgrads_range(x, 0, n_pend_a));             // head, tower and gate weight gradients
+    AR_HIP(hipStreamWaitEvent(x.side, ev_b2, 0));
+    TRY(flush_wgrads_range(x, n_pend_a, x.n_pend));      // expert layers n-1 .. 1
+    x.n_pend = 0;
+    TRY(flush_reductions(x));
     x.st = main_st;
-    TRY(flush_wgrads(x, false));                         // head, tower and gate weight gradients (the fork above covers them)
-    // 4a. row-wise trunk backward on the second side stream, beside the expert backward: it needs dcn / dlin (main stream,
-    // before the fork) and dq / deg (side stream) and WRITES de_out; the expert-L1 dgrad accumulates onto it later.
+    // 4a. row-wise trunk backward on the second side stream, beside the expert backward: it needs dcn / dlin and dq / deg
+    // (all ordered behind ev_gates on the side stream) and WRITES de_out; the expert-L1 dgrad accumulates onto it later.
     // (No stream ever waits on its own event and no two forked streams wait on each other: hipStreamEndCapture walks the
     // fork relation recursively and does not terminate on such a cycle.)
     hipEvent_t ev_rw = x.m->ev[x.ev_next++ % (x.m->n_ev - 1)];
@@ -876,22 +903,9 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
         LAUNCH(k_grp_bwd, dim3(1), dim3(256), ws + x.w.grp, grads + m->group_emb, cfg.n_tower[0], E, x.r, x.mp);
         x.st = main_st;
     }
-    phase_mark(x.st, 6);
-    // 5. experts; the first layer ADDS its input gradient onto de_out, which the row-wise backward (side2) has initialised
-    for (int j = nle - 1; j >= 0; --j) {
-        const float* in = j == 0 ? e_in : ws + x.w.ex[j - 1].Act;
-        float* d_in = j == 0 ? de_out : ws + x.w.ex[j - 1].dAct;
-        if (j == 0) {
-            // ---- side batch B (one fork): the deeper expert layers' weight gradients, then the split-K / bias reductions of
-            // everything queued so far, beside the first layer's backward: only that layer's reduction is left for the tail
-            TRY(flush_wgrads(x, true));
-            x.st = x.side;
-            TRY(flush_reductions(x));
-            x.st = main_st;
-            AR_HIP(hipStreamWaitEvent(x.st, ev_rw, 0));
-        }
-        TRY(layer_bwd(x, m->experts.L[j], x.w.ex[j], in, d_in, j == 0 ? 1 : 0, grads, -1, x.w.slab_ex[j]));
-    }
+    // 5b. the first expert layer ADDS its input gradient onto de_out, which the row-wise backward (side2) has initialised
+    AR_HIP(hipStreamWaitEvent(x.st, ev_rw, 0));
+    TRY(layer_bwd(x, m->experts.L[0], x.w.ex[0], e_in, de_out, 1, grads, -1, x.w.slab_ex[0]));
     phase_mark(x.st, 7);
     // ---- side batch C (one fork): the first expert layer's weight gradient and its reductions
     TRY(flush_wgrads(x, true));
@@ -899,14 +913,13 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     TRY(flush_reductions(x));
     x.st = main_st;
     if (c->l2_table && c->l2_dense_coef) {
-        // dense L2 terms behind the last reduction, on the SECOND side stream (it already holds the table term and the row-wise
-        // parameter gradients in stream order, and it only ever waits on the first side stream -- never the reverse: see 4a)
+        // (A/B only, measured slower) dense L2 terms behind the last reduction, on the SECOND side stream
         hipEvent_t e3 = x.m->ev[x.ev_next++ % (x.m->n_ev - 1)];
         AR_HIP(hipEventRecord(e3, x.side));
         AR_HIP(hipStreamWaitEvent(m->side2, e3, 0));
         TRY(aread_l2_dense(x.params, c->l2_dense_coef, m->n_params, grads, c->l2_reg_out, 1, m->side2));
     }
-    {   // the second side stream (row-wise parameter gradients, finished long ago) joins the main stream
+    {   // the second side stream (row-wise parameter gradients, table L2 sweep: finished long ago) joins the main stream
         hipEvent_t e2 = x.m->ev[x.ev_next++ % (x.m->n_ev - 1)];
         AR_HIP(hipEventRecord(e2, rw_stream));
         AR_HIP(hipStreamWaitEvent(main_st, e2, 0));
