@@ -283,6 +283,7 @@ class AREAD(HempMixin, nn.Module):
         self.l2_pass_early = os.environ.get("AREAD_L2_EARLY", "0") == "1"    # A/B: the sweep right after the row plan (round 1)
         self.l2_pass_in_backward = os.environ.get("AREAD_L2_IN_BWD", "1") == "1"   # default: issued by aread_backward beside the tower backward
         self.l2_dense_in_backward = os.environ.get("AREAD_L2_DENSE_IN_BWD", "0") == "1"   # A/B only
+        self.sort_early = os.environ.get("AREAD_SORT_EARLY", "0") == "1"                  # A/B: index sort issued before the forward (graph replay: +10 us)
         self.drop_seed = None          # set to an int to pin the dropout stream (tests)
         self._register_state_dict_hook(AREAD._sd_hook)
         self._register_load_state_dict_pre_hook(self._load_hook)
@@ -654,7 +655,13 @@ class AREAD(HempMixin, nn.Module):
                     bufs["reg"].zero_()
         if self.l2_pass_early:
             l2_pass()
-        if presort:
+        if presort and self.sort_early:
+            # the index sort of the embedding backward needs only the row plan: issued (captured) BEFORE the forward so that a
+            # graph replay schedules it beside the expert forward instead of behind everything else at the tail of the step
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self.embedding.sort_lookups(x, plan.sample_row)
+        elif presort:
             plan_ready = torch.cuda.Event()
             plan_ready.record(main)
         st, gate = self._run(x, 0, n_seg, domain_i, masks_dev, want_gates, y=y, seg_weight=seg_weight,
@@ -663,7 +670,7 @@ class AREAD(HempMixin, nn.Module):
         in_bwd = self.l2_pass_in_backward and not self.l2_pass_early and table_pass and with_reg
         if not self.l2_pass_early and not in_bwd:
             l2_pass()
-        if presort:
+        if presort and not self.sort_early:
             side.wait_event(plan_ready)
             with torch.cuda.stream(side):
                 self.embedding.sort_lookups(x, plan.sample_row)

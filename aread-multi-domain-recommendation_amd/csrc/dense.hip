@@ -658,7 +658,7 @@ static int flush_reductions(Ctx& x) {
 // one MLP layer backward.  d = dL/dAct on entry (in lw.dAct); on exit it holds dL/dH.
 static int g_fused_act_bn = -1;
 static int layer_bwd(Ctx& x, const LayerL& L, const LayerWs& lw, const float* in, float* d_in, int accumulate_d_in,
-                     float* grads, int level, int64_t slab_off) {
+                     float* grads, int level, int64_t slab_off, hipEvent_t before_dgrad = nullptr) {
     float* ws = x.ws;
     float* d = ws + lw.dAct;
     ActBwdP a = {};
@@ -693,6 +693,7 @@ static int layer_bwd(Ctx& x, const LayerL& L, const LayerWs& lw, const float* in
     const bool shared = L.in_gs == 0 && L.G > 1;
     const uint8_t* act = (level >= 0 && L.G > 1) ? level_active(x, level) : nullptr;
     // dgrad: d_in = dH W
+    if (d_in && before_dgrad) AR_HIP(hipStreamWaitEvent(x.st, before_dgrad, 0));   // (whoever initialises d_in for an accumulating dgrad)
     if (d_in) {
         GemmP g = {};
         g.A = d; g.lda = L.ncols; g.a_gs = L.out_dim;
@@ -852,30 +853,17 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
                     n_ge, 0, 1));
     hipEvent_t ev_gates = x.m->ev[x.ev_next++ % (x.m->n_ev - 1)];
     AR_HIP(hipEventRecord(ev_gates, x.side));
-    // head tails (partials of the heads backward), gate biases: all through misc_part, in this order on this one stream
-    LAUNCH(k_reduce_tiles, dim3(cdiv(m->n_heads * m->h_last, 32)), dim3(256), ws + x.w.misc_part, (int64_t)1024, m->n_heads * m->h_last,
-           grads + m->head_w + D, m->h_last, (int64_t)m->head_ld, 0, SUB, x.r);
-    LAUNCH(k_colsum, dim3(x.n_tiles), dim3(256), ws + x.w.dglogE, (int64_t)m->ld_ge, n_ge, ws + x.w.misc_part, (int64_t)1024, x.r);
-    LAUNCH(k_reduce_tiles, dim3(cdiv(n_ge, 32)), dim3(256), ws + x.w.misc_part, (int64_t)1024, n_ge, grads + m->gate_b, n_ge,
-           (int64_t)0, 0, 1, x.r);
-    if (m->gate_rows > 0) {
-        LAUNCH(k_colsum, dim3(x.n_tiles), dim3(256), ws + x.w.dglogT, (int64_t)m->ld_gt, m->gate_rows, ws + x.w.misc_part,
-               (int64_t)1024, x.r);
-        LAUNCH(k_reduce_tiles, dim3(cdiv(m->gate_rows, 32)), dim3(256), ws + x.w.misc_part, (int64_t)1024, m->gate_rows,
-               grads + m->tgate_b, m->gate_rows, (int64_t)0, 0, 1, x.r);
-    }
-    TRY(flush_wgrads_range(x, 0, n_pend_a));             // head, tower and gate weight gradients
-    AR_HIP(hipStreamWaitEvent(x.side, ev_b2, 0));
-    TRY(flush_wgrads_range(x, n_pend_a, x.n_pend));      // expert layers n-1 .. 1
-    x.n_pend = 0;
-    TRY(flush_reductions(x));
     x.st = main_st;
+    hipEvent_t ev_rw = x.m->ev[x.ev_next++ % (x.m->n_ev - 1)];
+    static int rw_early = -1, dgrad_wait_only = -1;
+    if (rw_early < 0) { const char* e = getenv("AREAD_RW_EARLY"); rw_early = e ? atoi(e) : 0; }
+    if (dgrad_wait_only < 0) { const char* e = getenv("AREAD_DGRAD_WAIT_ONLY"); dgrad_wait_only = e ? atoi(e) : 1; }
+    const hipStream_t rw_stream = m->side2;
+    auto issue_rowwise = [&]() -> int {
     // 4a. row-wise trunk backward on the second side stream, beside the expert backward: it needs dcn / dlin and dq / deg
     // (all ordered behind ev_gates on the side stream) and WRITES de_out; the expert-L1 dgrad accumulates onto it later.
     // (No stream ever waits on its own event and no two forked streams wait on each other: hipStreamEndCapture walks the
     // fork relation recursively and does not terminate on such a cycle.)
-    hipEvent_t ev_rw = x.m->ev[x.ev_next++ % (x.m->n_ev - 1)];
-    const hipStream_t rw_stream = m->side2;
     {
         AR_HIP(hipStreamWaitEvent(rw_stream, ev_gates, 0));
         x.st = rw_stream;
@@ -903,9 +891,35 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
         LAUNCH(k_grp_bwd, dim3(1), dim3(256), ws + x.w.grp, grads + m->group_emb, cfg.n_tower[0], E, x.r, x.mp);
         x.st = main_st;
     }
+        return AREAD_OK;
+    };
+    auto issue_side_rest = [&]() -> int {
+    x.st = x.side;
+    // head tails (partials of the heads backward), gate biases: all through misc_part, in this order on this one stream
+    LAUNCH(k_reduce_tiles, dim3(cdiv(m->n_heads * m->h_last, 32)), dim3(256), ws + x.w.misc_part, (int64_t)1024, m->n_heads * m->h_last,
+           grads + m->head_w + D, m->h_last, (int64_t)m->head_ld, 0, SUB, x.r);
+    LAUNCH(k_colsum, dim3(x.n_tiles), dim3(256), ws + x.w.dglogE, (int64_t)m->ld_ge, n_ge, ws + x.w.misc_part, (int64_t)1024, x.r);
+    LAUNCH(k_reduce_tiles, dim3(cdiv(n_ge, 32)), dim3(256), ws + x.w.misc_part, (int64_t)1024, n_ge, grads + m->gate_b, n_ge,
+           (int64_t)0, 0, 1, x.r);
+    if (m->gate_rows > 0) {
+        LAUNCH(k_colsum, dim3(x.n_tiles), dim3(256), ws + x.w.dglogT, (int64_t)m->ld_gt, m->gate_rows, ws + x.w.misc_part,
+               (int64_t)1024, x.r);
+        LAUNCH(k_reduce_tiles, dim3(cdiv(m->gate_rows, 32)), dim3(256), ws + x.w.misc_part, (int64_t)1024, m->gate_rows,
+               grads + m->tgate_b, m->gate_rows, (int64_t)0, 0, 1, x.r);
+    }
+    TRY(flush_wgrads_range(x, 0, n_pend_a));             // head, tower and gate weight gradients
+    AR_HIP(hipStreamWaitEvent(x.side, ev_b2, 0));
+    TRY(flush_wgrads_range(x, n_pend_a, x.n_pend));      // expert layers n-1 .. 1
+    x.n_pend = 0;
+    TRY(flush_reductions(x));
+    x.st = main_st;
+        return AREAD_OK;
+    };
+    if (rw_early) { TRY(issue_rowwise()); TRY(issue_side_rest()); }
+    else { TRY(issue_side_rest()); TRY(issue_rowwise()); }
     // 5b. the first expert layer ADDS its input gradient onto de_out, which the row-wise backward (side2) has initialised
-    AR_HIP(hipStreamWaitEvent(x.st, ev_rw, 0));
-    TRY(layer_bwd(x, m->experts.L[0], x.w.ex[0], e_in, de_out, 1, grads, -1, x.w.slab_ex[0]));
+    if (!dgrad_wait_only) AR_HIP(hipStreamWaitEvent(x.st, ev_rw, 0));
+    TRY(layer_bwd(x, m->experts.L[0], x.w.ex[0], e_in, de_out, 1, grads, -1, x.w.slab_ex[0], dgrad_wait_only ? ev_rw : nullptr));
     phase_mark(x.st, 7);
     // ---- side batch C (one fork): the first expert layer's weight gradient and its reductions
     TRY(flush_wgrads(x, true));
