@@ -236,6 +236,7 @@ extern "C" int aread_debug_phase_times(float* out_ms, int n) {
 
 static int g_fused_mode = -1;        // AREAD_FUSED_TOWERS: 0 = layer-by-layer launches (default: measured faster), 1 = fused tower forward
 static int g_n_cu = 0;
+static long long g_fused_fwd_calls = 0, g_fused_bwd_calls = 0;   // aread_debug_get: the tests check that the fused kernels really ran
 static int g_tf_stamps = 0;     // aread_debug_set("tf_stamps", 1): phase time stamps of k_tower_fwd into the workspace (tools/tf_stamps.py)
 static size_t tower_fwd_lds(const aread_model* m, TFwdP* p) {
     const aread_model_cfg& c = m->cfg;
@@ -333,6 +334,7 @@ static int tower_fused_fwd(Ctx& x, bool want_gates) {
     }
     AR_HIP(hipMemsetAsync(p.cnt, 0, (size_t)(AREAD_MAX_LEVEL * AREAD_MAX_LAYER * MAX_SEG + 16) * sizeof(unsigned), x.st));
     hipLaunchKernelGGL(k_tower_fwd, dim3(x.n_tiles), dim3(TF_THREADS), lds, x.st, p);
+    ++g_fused_fwd_calls;
     AR_LAUNCH_CHECK();
     return AREAD_OK;
 }
@@ -440,6 +442,7 @@ static int tower_fused_bwd(Ctx& x, float* grads) {
     }
     AR_HIP(hipMemsetAsync(p.cnt, 0, (size_t)(AREAD_MAX_LEVEL * AREAD_MAX_LAYER * MAX_SEG) * sizeof(unsigned), x.st));
     hipLaunchKernelGGL(k_tower_bwd, dim3(x.n_tiles), dim3(TF_THREADS), lds, x.st, p);
+    ++g_fused_bwd_calls;
     AR_LAUNCH_CHECK();
     // the side-stream consumers of what the kernel wrote: bias / gamma / beta reductions and weight gradients, tower by tower
     for (int l = LL; l >= 0; --l) {
@@ -958,6 +961,13 @@ extern "C" int aread_debug_set(const char* key, int value) {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&g_n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) g_n_cu = 0;
     }
     return AREAD_OK;
+}
+
+extern "C" long long aread_debug_get(const char* key) {
+    if (!key) return -1;
+    if (!strcmp(key, "fused_fwd_calls")) return g_fused_fwd_calls;
+    if (!strcmp(key, "fused_bwd_calls")) return g_fused_bwd_calls;
+    return -1;
 }
 
 extern "C" int aread_join(const aread_model* m, void* stream) {

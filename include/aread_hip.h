@@ -290,6 +290,8 @@ int aread_mlp_backward(const aread_model* m, const aread_mlp_call* call_host, co
 /* Test / A-B switch of the launch strategy (results agree to rounding): key "fused_towers" (0 = one launch per tower
  * layer, 1 = the fused tower pyramid of csrc/tower_fused.h), "wide_gemm" (0 / 1 / 2, csrc/gemm_wide.h).  Process-wide. */
 int aread_debug_set(const char* key, int value);
+/* Diagnostics: "fused_fwd_calls" / "fused_bwd_calls" = launches of the fused tower kernels so far in this process (-1: unknown key). */
+long long aread_debug_get(const char* key);
 /* Diagnostics: after aread_debug_set("phase_events", 1) the forward / backward record events at their phase boundaries on
  * the caller's stream; this returns the elapsed GPU time (ms) between consecutive boundaries of the last call. */
 int aread_debug_phase_times(float* out_ms, int n);

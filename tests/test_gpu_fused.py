@@ -104,6 +104,42 @@ def test_fused_tower_backward_matches_layerwise(dropout, B, p_active):
         assert d <= 2e-4 * np.abs(a[k]).max() + 1e-12, (k, d)
 
 
+@pytest.mark.parametrize("geom", [dict(n_tower=(2, 4, 8), n_expert=3, expert_dims=(128, 64, 32), tower_dims=((32, 16), (16, 8), (8, 8)),
+                                       n_domain=7),
+                                  dict(n_tower=(4, 4, 4), n_expert=5, expert_dims=(64, 64, 16), tower_dims=((16, 16), (16, 16), (16, 8)),
+                                       n_domain=3, field_dims=[40, 7, 3, 9, 11, 30, 10])])
+def test_fused_towers_other_geometries(geom):
+    """other tower / expert widths (8-wide layers, one k-step planes, 5 experts, equal-sized levels): fused forward + backward
+    against the layer-by-layer path on the whole step's outputs."""
+    import aread_amd
+    spec = spec_full(dropout=0.2, **geom)
+    rng = np.random.default_rng(41)
+    B = 1800
+    x = np.stack([rng.integers(0, d, B) for d in spec.field_dims]
+                 + [rng.integers(0, spec.field_dims[0] + 1, B) for _ in range(spec.n_mh_slots)], axis=1).astype(np.int32)
+    y = (rng.random(B) < 0.4).astype(np.float32)
+    masks = [O.random_valid_mask(spec, rng, 0.6) for _ in range(spec.n_domain)]
+    model, P = build_model(spec, 99, precision="bf16x3")
+    model.train()
+    model._stats0 = model.bn_stats.clone()
+    model.domain_mask = [[torch.tensor(np.asarray(m), dtype=torch.bool, device="cuda") for m in mk] for mk in masks]
+    md = aread_amd.pack_masks(masks, spec.n_domain, model.edge_num, "cuda")
+    from aread_amd import _lib as L
+    a = _run(model, x, y, md, 0, [])
+    n0 = (L.lib().aread_debug_get(b"fused_fwd_calls"), L.lib().aread_debug_get(b"fused_bwd_calls"))
+    b = _run(model, x, y, md, 1, [])
+    n1 = (L.lib().aread_debug_get(b"fused_fwd_calls"), L.lib().aread_debug_get(b"fused_bwd_calls"))
+    assert n1[0] == n0[0] + 1 and n1[1] == n0[1] + 1, "the fused kernels did not take this geometry"
+    assert b["err"] == 0
+    assert abs(a["loss"] - b["loss"]) <= 2e-6 * abs(a["loss"])
+    np.testing.assert_allclose(b["probs"], a["probs"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(b["gate"], a["gate"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(b["stats"], a["stats"], rtol=1e-4, atol=1e-6)
+    for k in ("gdense", "gtable"):
+        d = np.abs(b[k] - a[k]).max()
+        assert d <= 5e-4 * np.abs(a[k]).max() + 1e-9, (k, d)
+
+
 def test_fused_act_bn_backward_matches_two_pass():
     """k_act_bn_bwd (dropout/ReLU backward + BatchNorm backward of an expert layer in one launch, segment sums handed off in the
     kernel; off by default: measured slower) against the two-kernel sequence: identical gradients up to summation order."""
