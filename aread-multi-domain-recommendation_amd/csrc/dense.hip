@@ -361,13 +361,13 @@ static size_t tower_bwd_lds(const aread_model* m, TBwdP* p) {
     const int ldd = max_cols + 4;
     const size_t dbytes = up((size_t)TILE_M * ldd * 4);
     size_t scratch = (size_t)8 * 256 * 4;                                   // merge scratch
-    if ((size_t)2 * TILE_M * max_ngate * 4 > scratch) scratch = (size_t)2 * TILE_M * max_ngate * 4;   // mixing weights + dot products
+    if ((size_t)(2 * TILE_M + 16) * max_ngate * 4 > scratch) scratch = (size_t)(2 * TILE_M + 16) * max_ngate * 4;   // mixing weights + dot products + lane table
     if ((size_t)TILE_M * m->n_heads * 4 > scratch) scratch = (size_t)TILE_M * m->n_heads * 4;
     size_t abytes = up(max_blk_bytes > (int)scratch ? (size_t)max_blk_bytes : scratch);
     // the expert-output tile of the MMoE mix backward spans D1 + the A image region
     const int nle = m->experts.n_layers;
     const int wx = c.n_expert * m->experts.L[nle - 1].out_dim, ldx = wx + 4;
-    const size_t xbytes = (size_t)TILE_M * ldx * 4 + (size_t)2 * TILE_M * c.n_tower[0] * c.n_expert * 4;
+    const size_t xbytes = (size_t)TILE_M * ldx * 4 + (size_t)(2 * TILE_M + 16) * c.n_tower[0] * c.n_expert * 4;
     if (xbytes > dbytes + abytes) abytes = up(xbytes - dbytes);
     if (p) { p->lds_d0 = 0; p->lds_d1 = (int)dbytes; p->lds_aimg = (int)(2 * dbytes); p->ldd = ldd; p->ldx = ldx; }
     return 2 * dbytes + abytes;

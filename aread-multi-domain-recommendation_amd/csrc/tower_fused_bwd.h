@@ -392,16 +392,18 @@ __global__ __launch_bounds__(TF_THREADS) void k_tower_bwd(const TBwdP p) {
 #pragma unroll
                 for (int s = 0; s < 8; ++s) { g[s] = s < n_src ? __expf(g[s] - mx) : 0.f; den += g[s]; }
                 float sum = 0.f, am[8];
+                const float inv_den = 1.0f / den;
 #pragma unroll
-                for (int s = 0; s < 8; ++s) { g[s] = g[s] / den; am[s] = keep[s] ? g[s] : 0.f; sum += am[s]; }
+                for (int s = 0; s < 8; ++s) { g[s] = g[s] * inv_den; am[s] = keep[s] ? g[s] : 0.f; sum += am[s]; }
                 const float S = masked ? sum + GATE_EPS : 1.f;
+                const float inv_S = 1.0f / S;
                 float dot_ah = 0.f, ah[8];
 #pragma unroll
-                for (int s = 0; s < 8; ++s) { ah[s] = masked ? am[s] / S : g[s]; dot_ah += d[s] * ah[s]; }
+                for (int s = 0; s < 8; ++s) { ah[s] = masked ? am[s] * inv_S : g[s]; dot_ah += d[s] * ah[s]; }
                 float dot_a = 0.f, da[8];
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
-                    da[s] = !masked ? d[s] : keep[s] ? (d[s] - dot_ah) / S : 0.f;
+                    da[s] = !masked ? d[s] : keep[s] ? (d[s] - dot_ah) * inv_S : 0.f;
                     dot_a += s < n_src ? da[s] * g[s] : 0.f;
                 }
 #pragma unroll
@@ -435,9 +437,13 @@ __global__ __launch_bounds__(TF_THREADS) void k_tower_bwd(const TBwdP p) {
             *(float4*)(srcs + m * lds_ + c4 * 4) = *(const float4*)(src_g + (row0 + m) * wsrc + c4 * 4);
         }
         __syncthreads();
-        // dah[m][t][s] = dIn[m][t][:] . src[m][s][:]
+        TB_STAMP();                                          // mix: sources staged
+        // dah[m][t][s] = dIn[m][t][:] . src[m][s][:], one lane per product with the ROW as the fastest lane index: a wave reads
+        // 64 different rows of one (tower, source) pair, rows are ldd = 4 (mod 32) floats apart -> at most 2-way bank conflicts
+        // (tower-fastest order put 12 towers 64 B apart on two bank groups: 9 us instead of 3 at the last level; spreading a
+        // product over w/4 lanes with shuffles was slower still: 13 us)
         for (int it = tid; it < TILE_M * ngate; it += TF_THREADS) {
-            const int m = it / ngate, rem = it - m * ngate;
+            const int m = it & (TILE_M - 1), rem = it >> 6;
             const int t = rem / n_src, sidx = rem - t * n_src;
             float accd = 0.f;
             if (m < nvalid && act[t]) {
@@ -448,9 +454,10 @@ __global__ __launch_bounds__(TF_THREADS) void k_tower_bwd(const TBwdP p) {
                     accd += d4.x * x4.x + d4.y * x4.y + d4.z * x4.z + d4.w * x4.w;
                 }
             }
-            s_dah[it] = accd;
+            s_dah[m * ngate + rem] = accd;
         }
         __syncthreads();
+        TB_STAMP();                                          // mix: dot products
         for (int it = tid; it < TILE_M * n_t; it += TF_THREADS) {
             const int m = it / n_t, t = it - m * n_t;
             const int64_t row = row0 + m;
@@ -464,6 +471,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_tower_bwd(const TBwdP p) {
             gate_bwd(gl, s_dah + m * ngate + t * n_src, n_src, masked, mk, t, dgl, ahd);
         }
         __syncthreads();
+        TB_STAMP();                                          // mix: gate backward
         // d_src[m][s][:] = sum_t ah[m][t][s] * dIn[m][t][:]  -> over the source rows (level > 0: the next dcur) or dX
         const int w4 = w >> 2;
         for (int it = tid; it < TILE_M * n_src * w4; it += TF_THREADS) {

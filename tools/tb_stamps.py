@@ -27,7 +27,7 @@ names = ["start", "heads"]
 for l in (2, 1, 0):
     for j in (1, 0):
         names += [f"l{l}.{j} act+arrive", f"l{l}.{j} poll", f"l{l}.{j} merge", f"l{l}.{j} apply", f"l{l}.{j} img+dgrad"]
-    names += [f"l{l} mix bwd"]
+    names += [f"l{l} mix: stage", f"l{l} mix: dots", f"l{l} mix: gates", f"l{l} mix: d_src"]
 t = (raw[:, :len(names)] - raw[:, :1]) / 100.0
 d = np.diff(t, axis=1)
 print(f"{nt} tiles; kernel span (first start -> last end): {(raw[:, len(names) - 1].max() - raw[:, 0].min()) / 100.0:.1f} us; "
