@@ -343,6 +343,7 @@ class ShardedTableStep:
         self._zero17 = torch.zeros(emb.offsets.shape[0], dtype=torch.int32, device=dev)
         self._zero1 = torch.zeros(1, dtype=torch.int32, device=dev)
         self._ws = {}
+        self._pref, self._route_stream = None, None
         self._opt = None
         self._side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
 
@@ -369,10 +370,35 @@ class ShardedTableStep:
                                             L.stream()))
         return out
 
-    def lookup(self, x, plan):
-        """-> (route, unique rows); fills bufs['e'] (plan order)"""
+    def prefetch_route(self, x_next):
+        """Routing of the NEXT step's batch on its own stream while the current step runs: the variable-size all-to-all needs
+        2P counts on the host, and read inline that host read waits for everything queued before it -- the host can never
+        run ahead of the GPU and every step pays the launch latencies un-overlapped.  Read from the route stream it waits
+        only for the few routing kernels of the next batch.  x_next must keep its contents until the step that uses it.
+        Collective order: every rank calls prefetch_route at the same point of its step."""
+        emb = self.model.embedding
+        if self._route_stream is None:
+            self._route_stream = torch.cuda.Stream(device=x_next.device)
+        rs = self._route_stream
+        rs.wait_stream(torch.cuda.current_stream())                  # (x_next may have been produced on the main stream)
+        with torch.cuda.stream(rs):
+            route = self.router.route_hip(x_next, emb._offsets_dev(x_next.device))      # host read: waits for rs only
+            ev = torch.cuda.Event()
+            ev.record(rs)
+        self._pref = ((x_next.data_ptr(), tuple(x_next.shape)), route, ev)
+
+    def lookup(self, x, plan, x_key=None):
+        """-> (route, unique rows); fills bufs['e'] (plan order).  A prefetched route is used only when it was made for this
+        batch: x is the tensor given to prefetch_route, or x_key is that tensor's data_ptr() (x being a copy of it)."""
         L, emb, b = self._L, self.model.embedding, self.bufs
-        route = self.router.route_hip(x, emb._offsets_dev(x.device))
+        pref, self._pref = self._pref, None
+        if pref is not None and pref[0] == ((x.data_ptr() if x_key is None else int(x_key)), tuple(x.shape)):
+            route = pref[1]
+            torch.cuda.current_stream().wait_event(pref[2])
+            for t in (route.slot, route.recv_rows):
+                t.record_stream(torch.cuda.current_stream())
+        else:
+            route = self.router.route_hip(x, emb._offsets_dev(x.device))
         urows = self.router.fetch(route, self._gather_owned(route.recv_rows))
         L.check(L.lib().aread_embed_fwd(L.ptr(route.slot), x.shape[0], x.shape[1], L.ptr(self._zero17), L.ptr(urows),
                                         urows.shape[0], emb.embed_dim, emb.one_hot_field_num, emb.multi_hot_field_num,
@@ -415,12 +441,17 @@ class ShardedTableStep:
             L.check(lib.aread_embed_bwd_reduce(n, 1, emb.embed_dim, 1, L.ptr(g_recv), L.ptr(self.gshard),
                                                L.ptr(self._bwd_ws("o", n, 1)), L.stream()))
 
-    def step(self, x, y, masks_dev):
+    def step(self, x, y, masks_dev, next_x=None, x_key=None):
+        """next_x: the id tensor the NEXT call's batch comes from: its routing is prefetched while this step runs
+        (prefetch_route), which removes the host read from the step's critical path.  x_key: data_ptr() of the tensor this
+        call's x was copied from, when x is a staging copy (the prefetched route is matched by it)."""
         from .plan import RowPlan
         L, m, b = self._L, self.model, self.bufs
         lib = L.lib()
         plan = RowPlan(x, m.domain_idx, m.n_domain)
-        route, urows = self.lookup(x, plan)
+        route, urows = self.lookup(x, plan, x_key)
+        if next_x is not None:
+            self.prefetch_route(next_x)
         self.presort(x, route, plan)
         st = m.step_local(x, y, b, masks_dev=masks_dev, with_dense_l2=False, presort=False, plan=plan, e_ready=True,
                           l2_target=(self.shard.data, self.gshard))

@@ -44,6 +44,8 @@ def parse(argv=None):
     ap.add_argument("--domain-dist", default="proportional", choices=["proportional", "uniform"])
     ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3"],
                     help="GEMM arithmetic of the expert/tower forward+dgrad: exact fp32 MFMA or split-bf16 (3 products)")
+    ap.add_argument("--no-route-prefetch", action="store_true", help="sharded table: route every batch inline (host read on the "
+                    "critical path) instead of prefetching the next batch's routing during the current step")
     ap.add_argument("--step-only", action="store_true", help="profiling: run only the warm-up + timed steps (no roofline "
                     "micro-loops, no forward-only / fused-optimizer extras, no CPU baseline), so rocprofv3 sees the pure step")
     ap.add_argument("--kernels-only", action="store_true", help="profiling: one step to size the buffers, then only the "
@@ -224,6 +226,7 @@ def main():
     xs = torch.empty_like(batches[0][0])
     ys = torch.empty_like(batches[0][1])
     dp_state = {}
+    cur = {"i": 0}                                    # index of the batch the current step runs on (run_one keeps it)
     if use_dp:
         import aread_amd.dist as D
         D.FORCE_COLLECTIVES = world == 1              # --force-dp: still go through RCCL
@@ -232,7 +235,11 @@ def main():
         variants = {"replicated": (lambda: dp.step(xs, ys, masks_dev), bufs["total"])}
         if args.table != "replicated":
             sh = D.ShardedTableStep(model, B)
-            variants["sharded"] = (lambda: sh.step(xs, ys, masks_dev), sh.total)
+            # the routing (dedupe + split sizes, one host read) of the NEXT batch is prefetched on its own stream while this step
+            # runs -- an input-pipeline stage like the batch copy itself; it is executed inside the timed region, once per step
+            prefetch = not args.no_route_prefetch
+            variants["sharded"] = (lambda: sh.step(xs, ys, masks_dev, next_x=batches[(cur["i"] + 1) % n_batches][0] if prefetch else None,
+                                                   x_key=batches[cur["i"] % n_batches][0].data_ptr()), sh.total)
         dp_state["variant"] = "sharded" if args.table == "sharded" else "replicated"
 
         args.no_graph = True                          # the multi-GPU step is eager: collectives interleave with compute
@@ -278,6 +285,7 @@ def main():
             torch.cuda.synchronize()
 
     def run_one(i):
+        cur["i"] = i
         xb, yb = batches[i % n_batches][:2]
         xs.copy_(xb, non_blocking=True); ys.copy_(yb, non_blocking=True)
         if graph is not None:

@@ -82,6 +82,27 @@ def test_sharded_single_rank_matches_fused_step():
         gd = ref["gdense"]
         assert float((sh.gchunk[:n] - gd).abs().max()) <= 1e-6 * float(gd.abs().max())
         assert torch.equal(sh.full_table(), model.embedding.embedding_dict.weight.data)
+        # route prefetch: the routing of the next batch made on its own stream during this step gives the same step;
+        # a prefetched route is only used for the batch it was made for (x2 here), never for another one
+        g1, e1 = sh.gshard.clone(), sh.bufs["e"].clone()
+        x2 = torch.flip(x, dims=[0]).contiguous()
+        y2 = torch.flip(y, dims=[0]).contiguous()
+        model.drop_seed = 77
+        sh.step(x, y, md, next_x=x2)                                     # prefetches x2's routing
+        torch.cuda.synchronize()
+        assert torch.equal(sh.gshard, g1) and torch.equal(sh.bufs["e"], e1)
+        assert sh._pref is not None
+        sh.step(x, y, md)                                                # x again: the prefetched route must be ignored
+        torch.cuda.synchronize()
+        assert sh._pref is None and torch.equal(sh.gshard, g1) and torch.equal(sh.bufs["e"], e1)
+        sh.step(x2, y2, md)                                              # reference for x2, routed inline
+        torch.cuda.synchronize()
+        g2, e2 = sh.gshard.clone(), sh.bufs["e"].clone()
+        sh.prefetch_route(x2)
+        xs = x2.clone()                                                  # a staging copy, matched through x_key
+        sh.step(xs, y2, md, x_key=x2.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(sh.bufs["e"], e2) and torch.equal(sh.gshard, g2)
     finally:
         D.FORCE_COLLECTIVES = False
         dist.destroy_process_group()
