@@ -273,7 +273,11 @@ static bool tower_fused_ok(const Ctx& x) {
             g_n_cu = 0;
     }
     if (!g_fused_mode || c.precision != 1 || m->is_mlp) return false;
-    if (x.n_tiles > g_n_cu) return false;                    // every workgroup of a segment must be resident (one per CU)
+    // every workgroup of a segment must be resident (one per CU, ~150 KB of LDS each); keep a margin of CUs for whatever else
+    // holds LDS at the same time (RCCL's collective kernels in the multi-GPU step)
+    static int margin = -1;
+    if (margin < 0) { const char* e = getenv("AREAD_FUSED_CU_MARGIN"); margin = e ? atoi(e) : 32; }
+    if (x.n_tiles > g_n_cu - margin) return false;
     if (m->n_heads > MAX_TOWER || m->ld_h > 64) return false;
     int prev_w = m->experts.L[m->experts.n_layers - 1].out_dim;
     for (int l = 0; l < c.n_level; ++l) {
