@@ -235,6 +235,7 @@ extern "C" int aread_debug_phase_times(float* out_ms, int n) {
 }
 
 static int g_fused_mode = -1;        // AREAD_FUSED_TOWERS: 0 = layer-by-layer launches (default: measured faster), 1 = fused tower forward
+extern int g_plan_single;          // plan.hip
 static int g_n_cu = 0;
 static long long g_fused_fwd_calls = 0, g_fused_bwd_calls = 0;   // aread_debug_get: the tests check that the fused kernels really ran
 static int g_tf_stamps = 0;     // aread_debug_set("tf_stamps", 1): phase time stamps of k_tower_fwd into the workspace (tools/tf_stamps.py)
@@ -956,6 +957,7 @@ extern "C" int aread_debug_set(const char* key, int value) {
     if (!strcmp(key, "fused_towers")) g_fused_mode = value;
     else if (!strcmp(key, "fused_towers_bwd")) g_fused_bwd = value;
     else if (!strcmp(key, "fused_act_bn")) g_fused_act_bn = value;
+    else if (!strcmp(key, "plan_single")) g_plan_single = value;
     else if (!strcmp(key, "wide_gemm")) g_wide_mode = value;
     else if (!strcmp(key, "tf_stamps")) g_tf_stamps = value;
     else if (!strcmp(key, "phase_events")) g_phase_on = value;

@@ -1,6 +1,7 @@
 // plan.hip -- row plan: stable bucketing of samples by BN segment (domain) with tile padding.
 // Replaces the per-domain loaders and the host-side domain loop of run.py:310-353,609-611.
 #include "common.h"
+#include <cstdlib>
 
 #define PLAN_WAVES_PER_BLOCK 4
 #define PLAN_MAX_WAVES 2048
@@ -158,6 +159,106 @@ __global__ __launch_bounds__(PLAN_WAVES_PER_BLOCK * WAVE) void k_plan_rank(const
     }
 }
 
+// The same plan in ONE launch for batches of up to PLAN_SINGLE_MAX samples: a single 1024-thread workgroup (16 waves, each a
+// contiguous range of samples whose segment ids stay in registers between the counting and the ranking pass), the wave x segment
+// prefix in LDS.  Bit-identical tables.  MEASURED SLOWER than the three short launches (step +18 us: one workgroup walks the
+// whole strided id column and clears the tables alone), so it is off by default (AREAD_PLAN_SINGLE=1 for A/B); the plan test
+// covers it through the environment switch.
+#define PLAN_SINGLE_MAX 16384
+#define PLAN_SINGLE_IT (PLAN_SINGLE_MAX / 1024)
+__global__ __launch_bounds__(1024) void k_plan_single(const int32_t* __restrict__ x, PlanGeom g, int32_t* __restrict__ plan) {
+    __shared__ int s_part[16][MAX_SEG];
+    __shared__ int s_start[MAX_SEG];
+    __shared__ int s_bad[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int32_t* seg_count = plan + PLAN_HDR;
+    int32_t* seg_start = seg_count + MAX_SEG;
+    int32_t* tile_seg = seg_start + MAX_SEG;
+    int32_t* tile_valid = tile_seg + g.max_tiles;
+    int32_t* row_sample = tile_valid + g.max_tiles;
+    int32_t* sample_row = row_sample + g.max_rows;
+    for (int i = tid; i < g.max_rows; i += 1024) row_sample[i] = -1;
+    for (int i = tid; i < g.max_tiles; i += 1024) { tile_seg[i] = -1; tile_valid[i] = 0; }
+    const int per = ((g.B + 15) / 16 + WAVE - 1) / WAVE * WAVE;       // samples per wave, a multiple of 64
+    const int b0 = wave * per, b1 = min(g.B, b0 + per);
+    int seg[PLAN_SINGLE_IT];
+    int bad = 0;
+#pragma unroll
+    for (int it = 0; it < PLAN_SINGLE_IT; ++it) seg[it] = plan_seg_of(x, g, b0 + it * WAVE + lane, b1, bad);
+    int my_cnt = 0;
+#pragma unroll
+    for (int it = 0; it < PLAN_SINGLE_IT; ++it) {
+        if (b0 + it * WAVE >= b1) break;                               // wave-uniform
+        for (int v = 0; v < g.n_seg; ++v) {
+            const unsigned long long m = __ballot(seg[it] == v);
+            if (lane == v) my_cnt += __popcll(m);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o);
+    s_part[wave][lane] = my_cnt;
+    if (lane == 0) s_bad[wave] = bad;
+    // the table clears above and the table / row writes below hit the same addresses from different waves: have every
+    // clear acknowledged by the L2 before any wave passes the barrier (the workgroup-scope fence of __syncthreads alone
+    // relies on the in-order memory path of one CU)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid < MAX_SEG) {                                               // wave 0: lane = segment
+        int run = 0;
+        for (int j = 0; j < 16; ++j) { const int c = s_part[j][tid]; s_part[j][tid] = run; run += c; }
+        const int c = tid < g.n_seg ? run : 0;
+        const int nt = (c + TILE_M - 1) / TILE_M;
+        int incl = nt;
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) {
+            const int v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
+        }
+        const int first = incl - nt;
+        seg_count[tid] = c;
+        seg_start[tid] = first * TILE_M;
+        s_start[tid] = first * TILE_M;
+        for (int t = 0; t < nt; ++t) {
+            tile_seg[first + t] = tid;
+            const int v = c - t * TILE_M;
+            tile_valid[first + t] = v > TILE_M ? TILE_M : v;
+        }
+        const int total_tiles = __shfl(incl, WAVE - 1);
+        if (tid == 0) {
+            int nbad = 0;
+            for (int j = 0; j < 16; ++j) nbad += s_bad[j];
+            plan[PLAN_B] = g.B;
+            plan[PLAN_NSEG] = g.n_seg;
+            plan[PLAN_ROWS] = total_tiles * TILE_M;
+            plan[PLAN_NTILES] = total_tiles;
+            plan[PLAN_NBAD] = nbad;
+        }
+    }
+    __syncthreads();
+    int run = s_start[lane] + s_part[wave][lane];                      // next row of segment `lane` for this wave
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int it = 0; it < PLAN_SINGLE_IT; ++it) {
+        if (b0 + it * WAVE >= b1) break;
+        const int b = b0 + it * WAVE + lane;
+        const int s = seg[it];
+        unsigned long long mine = 0ull;
+        int add = 0;
+        for (int v = 0; v < g.n_seg; ++v) {
+            const unsigned long long m = __ballot(s == v);
+            if (s == v) mine = m;
+            if (lane == v) add = __popcll(m);
+        }
+        const int first = __shfl(run, s < 0 ? 0 : s);
+        if (s >= 0) {
+            const int r = first + __popcll(mine & lt);
+            row_sample[r] = b;
+            sample_row[b] = r;
+        }
+        run += add;
+    }
+}
+
 extern "C" int aread_plan_layout_get(int64_t B, int n_seg, aread_plan_layout* L) {
     AR_CHECK_ARG(L != nullptr, "aread_plan_layout_get: null output");
     AR_CHECK_ARG(B > 0 && n_seg >= 1 && n_seg <= MAX_SEG, "aread_plan_layout_get: bad B=%lld n_seg=%d", (long long)B, n_seg);
@@ -174,6 +275,7 @@ extern "C" int aread_plan_layout_get(int64_t B, int n_seg, aread_plan_layout* L)
     return AREAD_OK;
 }
 
+int g_plan_single = -1;     // AREAD_PLAN_SINGLE / aread_debug_set("plan_single", v)
 extern "C" int aread_plan_build(const int32_t* x, int64_t B, int f_in, int seg_col, int n_seg, int32_t* plan,
                                 void* stream) {
     AR_CHECK_ARG(plan != nullptr, "aread_plan_build: plan is null");
@@ -186,6 +288,13 @@ extern "C" int aread_plan_build(const int32_t* x, int64_t B, int f_in, int seg_c
     g.B = (int)B; g.f_in = f_in; g.seg_col = seg_col; g.n_seg = n_seg; g.max_rows = (int)mr; g.max_tiles = (int)(mr / TILE_M);
     g.n_waves = plan_waves(B); g.per_wave = plan_per_wave(B, g.n_waves);
     const hipStream_t st = (hipStream_t)stream;
+    int& single = g_plan_single;
+    if (single < 0) { const char* e = getenv("AREAD_PLAN_SINGLE"); single = e ? atoi(e) : 0; }   // measured +18 us per step: off
+    if (single && B <= PLAN_SINGLE_MAX) {
+        hipLaunchKernelGGL(k_plan_single, dim3(1), dim3(1024), 0, st, x, g, plan);
+        AR_LAUNCH_CHECK();
+        return AREAD_OK;
+    }
     const unsigned blocks = (unsigned)((g.n_waves + PLAN_WAVES_PER_BLOCK - 1) / PLAN_WAVES_PER_BLOCK);
     hipLaunchKernelGGL(k_plan_count, dim3(blocks), dim3(PLAN_WAVES_PER_BLOCK * WAVE), 0, st, x, g, plan);
     AR_LAUNCH_CHECK();

@@ -5,7 +5,7 @@ csv.field_size_limit(1 << 30)
 f = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[-1]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith(("k_plan_count", "k_plan_build"))]
+idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith(("k_plan_count", "k_plan_build", "k_plan_single"))]
 s, e = idx[-3], idx[-2]
 t0 = int(rows[s]["Start_Timestamp"])
 print("step wall (plan to plan): %.1f us" % ((int(rows[e]["Start_Timestamp"]) - t0) / 1e3))
