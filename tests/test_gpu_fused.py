@@ -140,6 +140,51 @@ def test_fused_towers_other_geometries(geom):
         assert d <= 5e-4 * np.abs(a[k]).max() + 1e-9, (k, d)
 
 
+@pytest.mark.parametrize("mode", ["wo_mask", "domain_with_mask"])
+def test_fused_towers_dropin_autograd_path(mode):
+    """the drop-in forward()/autograd path (one segment, external dL/dprobs through k_heads_dz, wo_mask = unmasked gates):
+    fused forward + backward against the layer-by-layer kernels on predictions and every gradient."""
+    from aread_amd import _lib as L
+    spec = spec_full(dropout=0.2)
+    rng = np.random.default_rng(17)
+    x, _ = _batch(spec, rng, 900, ragged=False)
+    x[:, spec.domain_idx] = 2
+    y = torch.from_numpy((rng.random(900) < 0.5).astype(np.float32)).cuda()
+    masks = [O.random_valid_mask(spec, rng, 0.5) for _ in range(spec.n_domain)]
+    model, P = build_model(spec, 123, precision="bf16x3")
+    model.domain_mask = [[torch.tensor(np.asarray(m), dtype=torch.bool, device="cuda") for m in mk] for mk in masks]
+    xd = torch.from_numpy(x).cuda()
+    stats0 = model.bn_stats.clone()
+    res = []
+    n0 = (L.lib().aread_debug_get(b"fused_fwd_calls"), L.lib().aread_debug_get(b"fused_bwd_calls"))
+    try:
+        for fused in (0, 1):
+            L.check(L.lib().aread_debug_set(b"fused_towers", fused))
+            L.check(L.lib().aread_debug_set(b"fused_towers_bwd", fused))
+            model.bn_stats.copy_(stats0)
+            model.train(); model.drop_seed = 5
+            model.reset_for_mask_update()
+            model.zero_grad()
+            pred = model(xd, mode=mode, domain_i=2, memory_gate_value=(mode == "wo_mask"))
+            loss = torch.nn.BCELoss()(pred.squeeze(), y) + model.get_regularization_loss(device="cuda")
+            loss.backward()
+            torch.cuda.synchronize()
+            grads = {n: p.grad.detach().cpu().numpy().copy() for n, p in model.named_parameters() if p.grad is not None}
+            res.append((pred.detach().cpu().numpy().copy(), float(loss.detach()), grads))
+    finally:
+        L.check(L.lib().aread_debug_set(b"fused_towers", 1))
+        L.check(L.lib().aread_debug_set(b"fused_towers_bwd", 1))
+    n1 = (L.lib().aread_debug_get(b"fused_fwd_calls"), L.lib().aread_debug_get(b"fused_bwd_calls"))
+    assert n1[0] > n0[0] and n1[1] > n0[1], "the fused kernels did not run on the drop-in path"
+    (pa, la, ga), (pb, lb, gb) = res
+    np.testing.assert_allclose(pb, pa, rtol=1e-4, atol=1e-6)
+    assert abs(la - lb) <= 2e-6 * abs(la)
+    assert set(ga) == set(gb)
+    for n in ga:
+        d = np.abs(gb[n] - ga[n]).max()
+        assert d <= 5e-4 * np.abs(ga[n]).max() + 1e-9, (n, d)
+
+
 def test_fused_act_bn_backward_matches_two_pass():
     """k_act_bn_bwd (dropout/ReLU backward + BatchNorm backward of an expert layer in one launch, segment sums handed off in the
     kernel; off by default: measured slower) against the two-kernel sequence: identical gradients up to summation order."""
