@@ -318,6 +318,7 @@ static int tower_fused_fwd(Ctx& x, bool want_gates) {
             T.bias = P + L.b; T.gamma = P + L.gamma; T.beta = P + L.beta;
             T.rmean = c->stats + L.rmean; T.rvar = c->stats + L.rvar;
             T.H = ws + lw.H; T.Act = ws + lw.Act; T.part = ws + lw.part; T.mean = ws + lw.mean; T.rstd = ws + lw.rstd; T.var = ws + lw.var;
+            T.tags = (tf_u64*)(ws + lw.tag_f);
         }
     }
     const int nle = m->experts.n_layers;
@@ -337,7 +338,6 @@ static int tower_fused_fwd(Ctx& x, bool want_gates) {
         AR_HIP(hipFuncSetAttribute((const void*)k_tower_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_set = lds;
     }
-    AR_HIP(hipMemsetAsync(p.cnt, 0, (size_t)(AREAD_MAX_LEVEL * AREAD_MAX_LAYER * MAX_SEG + 16) * sizeof(unsigned), x.st));
     hipLaunchKernelGGL(k_tower_fwd, dim3(x.n_tiles), dim3(TF_THREADS), lds, x.st, p);
     ++g_fused_fwd_calls;
     AR_LAUNCH_CHECK();
@@ -425,6 +425,7 @@ static int tower_fused_bwd(Ctx& x, float* grads) {
             T.gamma = P + L.gamma; T.beta = P + L.beta;
             T.H = ws + lw.H; T.mean = ws + lw.mean; T.rstd = ws + lw.rstd;
             T.dH = ws + lw.dAct; T.bpart = ws + lw.bpart; T.cpart = ws + lw.cpart;
+            T.tags = (tf_u64*)(ws + lw.tag_b);
         }
     }
     p.X = ws + x.w.ex[nle - 1].Act; p.n_exp = cfg.n_expert; p.xw = m->experts.L[nle - 1].out_dim; p.dX = ws + x.w.ex[nle - 1].dAct;
@@ -445,7 +446,9 @@ static int tower_fused_bwd(Ctx& x, float* grads) {
         AR_HIP(hipFuncSetAttribute((const void*)k_tower_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_set = lds;
     }
-    AR_HIP(hipMemsetAsync(p.cnt, 0, (size_t)(AREAD_MAX_LEVEL * AREAD_MAX_LAYER * MAX_SEG) * sizeof(unsigned), x.st));
+    if (!m->bwd_tags_clean)                                  // a second backward on one forward: the tags of the first are stale
+        AR_HIP(hipMemsetAsync(ws + x.w.tf_tags, 0, (size_t)x.w.tf_tags_floats * sizeof(float), x.st));
+    m->bwd_tags_clean = false;
     hipLaunchKernelGGL(k_tower_bwd, dim3(x.n_tiles), dim3(TF_THREADS), lds, x.st, p);
     ++g_fused_bwd_calls;
     AR_LAUNCH_CHECK();
@@ -503,6 +506,12 @@ extern "C" int aread_forward(const aread_model* m, const aread_call* c, const fl
         x.st = x.side;
         LAUNCH(k_mask_prep, dim3(1), dim3(256), mp);
         if (cfg.precision == 1 && fused_towers && !wide_any()) TRY(prepare_wimg(x, 0));   // (the fused tower kernel reads them after the join)
+        if (fused_towers) {
+            // hand-off granules of the fused tower kernels (forward AND backward of this step) and the error word: zero tags
+            AR_HIP(hipMemsetAsync(ws + x.w.tf_tags, 0, (size_t)x.w.tf_tags_floats * sizeof(float), x.st));
+            AR_HIP(hipMemsetAsync((unsigned*)(ws + x.w.tf_sync) + AREAD_MAX_LEVEL * AREAD_MAX_LAYER * MAX_SEG, 0, 16 * sizeof(unsigned), x.st));
+            m->bwd_tags_clean = true;
+        }
         if (c->probs) AR_HIP(hipMemsetAsync(c->probs, 0, (size_t)m->n_heads * c->B * sizeof(float), x.st));
         if (c->train && cfg.precision == 1) {
             TRY(transpose_weights(x));

@@ -284,6 +284,14 @@ void ws_layout(const aread_model* m, int64_t B, int n_seg, WsLayout* w) {
     w->misc_part = take(&o, tiles * 4 * 1024);
     w->tf_sync = take(&o, 2 * (AREAD_MAX_LEVEL * AREAD_MAX_LAYER * MAX_SEG + 64));
     w->ab_sync = take(&o, AREAD_MAX_LAYER * 16 * MAX_SEG);      // arrival counters of k_act_bn_bwd: [layer][<= 16 column chunks][segment]
+    w->tf_tags = o;
+    for (int l = 0; l < c.n_level; ++l)
+        for (int j = 0; j < m->towers[l].n_layers; ++j) {
+            const LayerL& L = m->towers[l].L[j];
+            w->tw[l][j].tag_f = take(&o, tiles * L.ncols * 4);
+            w->tw[l][j].tag_b = take(&o, tiles * L.ncols * 4);
+        }
+    w->tf_tags_floats = o - w->tf_tags;
     w->total = o;
 }
 

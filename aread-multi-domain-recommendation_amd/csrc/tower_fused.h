@@ -12,11 +12,11 @@
 //   MFMA    : v_mfma_f32_16x16x32_bf16 x3 (hi*hi + hi*lo + lo*hi), operands swapped (weights as the A input) so that a
 //             lane holds 4 consecutive columns of one row; a "unit" = (tower, 16-column fragment) x 64 rows, units are
 //             dealt round-robin to the 4 waves, so the column statistics of a unit never leave its wave
-//   stats   : (mean, M2) of the tile per column -> global partials with write-through (sc1) 8-byte stores, one agent-scope
-//             counter add per workgroup, relaxed sc1 poll until the segment's tiles have all arrived, then every
-//             workgroup of the segment merges the partials (Chan, tile order) -- MI355X guide, Guideline 16 / "Valid
-//             forms": all payload stores and loads are sc1, every storing wave drains vmcnt before the barrier that
-//             precedes the counter add; the spin is bounded and raises an error word instead of hanging
+//   stats   : (mean, M2) of the tile per column -> two data-tagged 8-byte granules {tag, value} per column, each ONE relaxed
+//             agent-scope (sc1) store; every workgroup of the segment then merges the partials itself (Chan, tile order): a
+//             thread sweeps the granules of its (column, tile group) item with sc1 loads until every tag matches -- MI355X
+//             guide, Guideline 16 R2: the data is the flag, no drain / counter / poll / barrier; the sweep is bounded and
+//             raises an error word instead of hanging; the tags are zeroed before every step (aread_forward, side stream)
 //   apply   : normalise + ReLU + dropout in registers; H (pre-BN) and Act go to the workspace exactly where the backward
 //             pass expects them; Act also stays in LDS (fp32) for the next A image, the next level's mix, or the heads.
 // All workgroups of a segment must be resident together: the launcher only takes this path when the tile count fits the
@@ -35,6 +35,7 @@
 #define TF_MAX_SEG_TILES 256           // tiles of one segment whose row counts are cached in LDS
 #define TF_MERGE_Q 12                  // partial loads in flight per (column, tile group): covers segments of <= 24 tiles at two groups
 
+typedef unsigned long long tf_u64;
 struct TFLayer {
     int n_t, in_w, out_w, ncols;        // towers of the level, per-tower input / output width, n_t*out_w
     int ks, nfr, pk;                    // 32-wide k-steps, 16-wide column fragments per tower, stored 8-wide planes per k-step
@@ -44,6 +45,7 @@ struct TFLayer {
     const float* bias; const float* gamma; const float* beta;
     const float* rmean; const float* rvar;
     float* H; float* Act; float* part; float* mean; float* rstd; float* var;
+    tf_u64* tags;                       // [n_tiles][ncols][2] data-tagged (mean, M2) granules of the in-kernel hand-off
 };
 
 struct TFwdP {
@@ -65,7 +67,6 @@ struct TFwdP {
     RowsP r; ModeP mp;
 };
 
-typedef unsigned long long tf_u64;
 __device__ __forceinline__ void tf_store_sc1(float* p, float a, float b) {
     union { float f[2]; tf_u64 u; } v;
     v.f[0] = a; v.f[1] = b;
@@ -75,6 +76,21 @@ __device__ __forceinline__ void tf_load_sc1(const float* p, float& a, float& b) 
     union { float f[2]; tf_u64 u; } v;
     v.u = __hip_atomic_load((const tf_u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     a = v.f[0]; b = v.f[1];
+}
+
+// Data-tagged hand-off granules (MI355X guide, Guideline 16 R2): one naturally aligned 8-byte {tag, value} word written by ONE
+// relaxed agent-scope (sc1) store and read by relaxed sc1 loads until the tag matches -- the data is the flag: no drain, no
+// counter, no poll.  A (mean, M2) resp. (sum, sum) pair is two granules.  The tag words are zeroed before every step.
+#define TF_TAG 0x5A17u
+__device__ __forceinline__ void tf_put_tagged(tf_u64* g, float a, float b) {
+    __hip_atomic_store(g, ((tf_u64)TF_TAG << 32) | __float_as_uint(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(g + 1, ((tf_u64)TF_TAG << 32) | __float_as_uint(b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool tf_get_tagged(const tf_u64* g, float& a, float& b) {
+    const tf_u64 x0 = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const tf_u64 x1 = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a = __uint_as_float((unsigned)x0); b = __uint_as_float((unsigned)x1);
+    return (unsigned)(x0 >> 32) == TF_TAG && (unsigned)(x1 >> 32) == TF_TAG;
 }
 
 // (hi, lo) split of 8 consecutive floats into one 16-byte slot of each image
@@ -391,19 +407,13 @@ __global__ __launch_bounds__(TF_THREADS) void k_tower_fwd(const TFwdP p) {
                         m2[r] = s;
                     }
                     if (fr == 0 && cok) {
-                        float* o = L.part + ((int64_t)tile * ncols + col) * 2;
+                        tf_u64* o = L.tags + ((int64_t)tile * ncols + col) * 2;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) tf_store_sc1(o + 2 * r, mean[r], m2[r]);
+                        for (int r = 0; r < 4; ++r) tf_put_tagged(o + 2 * r, mean[r], m2[r]);
                     }
                 }
             }
-            unsigned* ctr = p.cnt + (size_t)(l * p.n_layers + j) * MAX_SEG + seg;
-            if (sync_stats) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its sc1 partial stores
-                __syncthreads();
-                if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            TF_STAMP();                                      // stats + drain + arrive
+            TF_STAMP();                                      // stats published
             if (j + 1 == p.n_layers && l + 1 < p.n_level) compute_gates(l + 1);
             // H (pre-BatchNorm, the backward reads it) drains while the other tiles of the segment arrive
 #pragma unroll
@@ -418,14 +428,6 @@ __global__ __launch_bounds__(TF_THREADS) void k_tower_fwd(const TFwdP p) {
             }
             // ---- statistics of the segment -------------------------------------------------------------------------------
             if (sync_stats) {
-                if (tid == 0) {
-                    unsigned spins = 0;
-                    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nt) {
-                        __builtin_amdgcn_s_sleep(2);
-                        if (++spins > TF_SPIN_LIMIT) { __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                    }
-                }
-                __syncthreads();
                 TF_STAMP();                                  // H stores issued + poll
                 // merge the partials of the segment's tiles (Chan): item = (column, tile quarter q: tiles q, q+4, ...), every
                 // load of an item in flight at once, then the four quarters are combined in order -- the order of k_bn_act
@@ -437,11 +439,19 @@ __global__ __launch_bounds__(TF_THREADS) void k_tower_fwd(const TFwdP p) {
                     float n = 0.f, mean = 0.f, m2 = 0.f;
                     if (item < nq * ncols && act[c / out_w]) {
                         float mb[TF_MERGE_Q], qb[TF_MERGE_Q];
+                        bool have[TF_MERGE_Q];
 #pragma unroll
-                        for (int i = 0; i < TF_MERGE_Q; ++i) {
-                            const int t = q + nq * i;
-                            mb[i] = 0.f; qb[i] = 0.f;
-                            if (t < nt) tf_load_sc1(L.part + ((int64_t)(t0 + t) * ncols + c) * 2, mb[i], qb[i]);
+                        for (int i = 0; i < TF_MERGE_Q; ++i) { mb[i] = 0.f; qb[i] = 0.f; have[i] = q + nq * i >= nt; }
+                        for (unsigned spins = 0;;) {             // sweep this item's granules until every tag matches
+                            bool all = true;
+#pragma unroll
+                            for (int i = 0; i < TF_MERGE_Q; ++i) {
+                                if (!have[i]) have[i] = tf_get_tagged(L.tags + ((int64_t)(t0 + q + nq * i) * ncols + c) * 2, mb[i], qb[i]);
+                                all = all && have[i];
+                            }
+                            if (all) break;
+                            __builtin_amdgcn_s_sleep(1);
+                            if (++spins > TF_SPIN_LIMIT) { __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                         }
 #pragma unroll
                         for (int i = 0; i < TF_MERGE_Q; ++i) {
@@ -455,8 +465,11 @@ __global__ __launch_bounds__(TF_THREADS) void k_tower_fwd(const TFwdP p) {
                             }
                         }
                         for (int t = q + nq * TF_MERGE_Q; t < nt; t += nq) {    // very long segments
-                            float mbx, qbx;
-                            tf_load_sc1(L.part + ((int64_t)(t0 + t) * ncols + c) * 2, mbx, qbx);
+                            float mbx = 0.f, qbx = 0.f;
+                            for (unsigned spins = 0; !tf_get_tagged(L.tags + ((int64_t)(t0 + t) * ncols + c) * 2, mbx, qbx);) {
+                                __builtin_amdgcn_s_sleep(1);
+                                if (++spins > TF_SPIN_LIMIT) { __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                            }
                             const float nb = t < TF_MAX_SEG_TILES ? s_tv[t] : (float)p.r.tile_valid[t0 + t];
                             const float tot = n + nb, delta = mbx - mean, rt = __builtin_amdgcn_rcpf(tot);
                             mean += delta * (nb * rt);

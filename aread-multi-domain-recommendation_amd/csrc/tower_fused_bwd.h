@@ -7,8 +7,8 @@
 // the head partials, and dX for the expert backward.
 //
 // One workgroup (TF_THREADS threads) owns one 64-row plan tile.  The BatchNorm backward needs, per column, the sums of
-// dyhat and dyhat*xhat over the SEGMENT: the same in-kernel hand-off as the forward (sc1 partial stores -- into bpart
-// itself --, one agent-scope counter add per workgroup, bounded relaxed poll, fixed-order merge).
+// dyhat and dyhat*xhat over the SEGMENT: the same in-kernel hand-off as the forward (data-tagged 8-byte granules, swept by the
+// merging threads until every tag matches; bpart is written as well, for the reductions on the side stream).
 // LDS: two fp32 row buffers D0 / D1 [64][ldd] that alternate between "current gradient" and "xhat / next gradient", the
 // split-bf16 A image of dH for the dgrad MFMA, and small per-column arrays; gate scratch and merge scratch alias the A
 // image region, the expert-output tile of the MMoE mix backward spans D1 + the A image region.
@@ -23,6 +23,7 @@ struct TBLayer {
     const float* gamma; const float* beta;
     const float* H; const float* mean; const float* rstd;
     float* dH; float* bpart; float* cpart;
+    tf_u64* tags;                       // [n_tiles][ncols][2] data-tagged (sum dyhat, sum dyhat*xhat) granules of the hand-off
 };
 
 struct TBwdP {
@@ -209,27 +210,18 @@ __global__ __launch_bounds__(TF_THREADS) void k_tower_bwd(const TBwdP p) {
             for (int i = 0; i < 4; ++i)
                 for (int o = 1; o < R; o <<= 1) { a1[i] += __shfl_xor(a1[i], o); a2[i] += __shfl_xor(a2[i], o); }
             if (qon && rg == 0) {
-                float* o = L.bpart + ((int64_t)tile * ncols + c) * 2;
+                float* o = L.bpart + ((int64_t)tile * ncols + c) * 2;      // (the bias / gamma / beta reductions read these later)
+                *(float4*)o = make_float4(a1[0], a2[0], a1[1], a2[1]);
+                *(float4*)(o + 4) = make_float4(a1[2], a2[2], a1[3], a2[3]);
+                if (p.train && bn) {
+                    tf_u64* tg = L.tags + ((int64_t)tile * ncols + c) * 2;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) tf_store_sc1(o + 2 * i, a1[i], a2[i]);
-            }
-            unsigned* ctr = p.cnt + (size_t)(l * p.n_layers + j) * MAX_SEG + seg;
-            if (sync_stats) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its sc1 partial stores
-                __syncthreads();
-                if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int i = 0; i < 4; ++i) tf_put_tagged(tg + 2 * i, a1[i], a2[i]);
+                }
             }
             TB_STAMP();                                      // act backward + arrive
             // ---- B. segment sums ---------------------------------------------------------------------------------------------
             if (sync_stats) {
-                if (tid == 0) {
-                    unsigned spins = 0;
-                    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nt) {
-                        __builtin_amdgcn_s_sleep(2);
-                        if (++spins > TF_SPIN_LIMIT) { __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                    }
-                }
-                __syncthreads();
                 TB_STAMP();                                  // poll
                 // item = (column, tile group q of nqg): plain sums in tile order inside a group, groups combined in order
                 const int nqg = 4 * ncols <= TF_THREADS ? 4 : 2 * ncols <= TF_THREADS ? 2 : 1;
@@ -240,17 +232,28 @@ __global__ __launch_bounds__(TF_THREADS) void k_tower_bwd(const TBwdP p) {
                     float t1 = 0.f, t2 = 0.f;
                     if (item < nqg * ncols && act[cc / out_w]) {
                         float b1[TF_MERGE_Q], b2[TF_MERGE_Q];
+                        bool have[TF_MERGE_Q];
 #pragma unroll
-                        for (int i = 0; i < TF_MERGE_Q; ++i) {
-                            const int t = q + nqg * i;
-                            b1[i] = 0.f; b2[i] = 0.f;
-                            if (t < nt) tf_load_sc1(L.bpart + ((int64_t)(t0 + t) * ncols + cc) * 2, b1[i], b2[i]);
+                        for (int i = 0; i < TF_MERGE_Q; ++i) { b1[i] = 0.f; b2[i] = 0.f; have[i] = q + nqg * i >= nt; }
+                        for (unsigned spins = 0;;) {             // sweep this item's granules until every tag matches
+                            bool all = true;
+#pragma unroll
+                            for (int i = 0; i < TF_MERGE_Q; ++i) {
+                                if (!have[i]) have[i] = tf_get_tagged(L.tags + ((int64_t)(t0 + q + nqg * i) * ncols + cc) * 2, b1[i], b2[i]);
+                                all = all && have[i];
+                            }
+                            if (all) break;
+                            __builtin_amdgcn_s_sleep(1);
+                            if (++spins > TF_SPIN_LIMIT) { __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                         }
 #pragma unroll
                         for (int i = 0; i < TF_MERGE_Q; ++i) { t1 += b1[i]; t2 += b2[i]; }
                         for (int t = q + nqg * TF_MERGE_Q; t < nt; t += nqg) {
-                            float x1, x2;
-                            tf_load_sc1(L.bpart + ((int64_t)(t0 + t) * ncols + cc) * 2, x1, x2);
+                            float x1 = 0.f, x2 = 0.f;
+                            for (unsigned spins = 0; !tf_get_tagged(L.tags + ((int64_t)(t0 + t) * ncols + cc) * 2, x1, x2);) {
+                                __builtin_amdgcn_s_sleep(1);
+                                if (++spins > TF_SPIN_LIMIT) { __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                            }
                             t1 += x1; t2 += x2;
                         }
                     }
