@@ -329,7 +329,7 @@ static int tower_fused_fwd(Ctx& x, bool want_gates) {
     p.ld_h = m->ld_h; p.h_last = m->h_last;
     p.z = ws + x.w.z; p.prob = ws + x.w.prob; p.dz = ws + x.w.dz; p.probs_out = c->probs; p.B = c->B;
     p.y = c->y; p.seg_weight = c->seg_weight; p.loss_part = (c->y && c->loss_out) ? ws + x.w.loss_part : nullptr;
-    p.cnt = (unsigned*)(ws + x.w.tf_sync); p.err = p.cnt + AREAD_MAX_LEVEL * AREAD_MAX_LAYER * MAX_SEG;
+    p.err = (unsigned*)(ws + x.w.tf_sync) + AREAD_MAX_LEVEL * AREAD_MAX_LAYER * MAX_SEG;
     p.stamps = g_tf_stamps ? (unsigned long long*)(ws + x.w.misc_part) : nullptr;   // diagnostics: misc_part is free during the forward
     p.r = x.r; p.mp = x.mp;
     const size_t lds = tower_fwd_lds(m, &p);
@@ -434,7 +434,6 @@ static int tower_fused_bwd(Ctx& x, float* grads) {
     p.dz = ws + x.w.dz; p.actLast = ws + x.w.tw[LL][m->towers[LL].n_layers - 1].Act;
     p.head_w = P + m->head_w; p.head_ld = m->head_ld; p.D = m->D; p.n_heads = m->n_heads; p.ld_h = m->ld_h; p.h_last = m->h_last;
     p.dlin = ws + x.w.dlin; p.head_part = ws + x.w.misc_part; p.ld_hp = 1024;
-    p.cnt = (unsigned*)(ws + x.w.tf_sync) + AREAD_MAX_LEVEL * AREAD_MAX_LAYER * MAX_SEG + 64;
     p.err = (unsigned*)(ws + x.w.tf_sync) + AREAD_MAX_LEVEL * AREAD_MAX_LAYER * MAX_SEG;     // the forward's error word
     p.stamps = g_tf_stamps == 2 ? (unsigned long long*)(ws + x.w.gate_part) : nullptr;        // diagnostics only
     p.r = x.r; p.mp = x.mp;

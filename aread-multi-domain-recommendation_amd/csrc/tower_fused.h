@@ -1,17 +1,17 @@
 // tower_fused.h -- the whole HEI tower pyramid of the FORWARD pass in one launch (split-bf16 mode):
 //   MMoE mix (aread.py:152-153) -> per level { masked gate mix (aread.py:282-295), [Linear -> BatchNorm -> ReLU -> Dropout] x
 //   n_layers (layer.py:203-229) } -> heads + sigmoid + bagging BCE and its gradient (aread.py:304-310, run.py:672-677).
-// It replaces k_mix0, k_mixl, the tower GEMMs, k_bn_act and k_heads_fwd: 16 dependent launches of 5-20 us each for 7 % of
+// It replaces k_mix0, k_mixl, the tower GEMMs, k_bn_act and k_heads_fwd: 19 dependent launches of 5-12 us each for 7 % of
 // the step's FLOPs become one launch whose BatchNorm statistics points are segment-scoped hand-offs INSIDE the kernel.
 //
-// One workgroup (256 threads, 4 waves) owns one 64-row plan tile for every tower of every level; a tile lies inside one
+// One workgroup (512 threads, 8 waves) owns one 64-row plan tile for every tower of every level; a tile lies inside one
 // segment (domain), so the edge mask and the "tower is active" predicate are workgroup-uniform.  Per layer:
 //   A image : the layer input of all towers as split-bf16 (hi, lo) tiles in LDS, per (tower, 32-wide k-step) one block in
 //             the layout of gemm.h::bf3_off (conflict-free ds_read_b128 fragments); K is zero-padded to 32
 //   weights : fragments straight from the pre-tiled images k_prep_wimg wrote for this step (L2-resident, 139 KB in all)
 //   MFMA    : v_mfma_f32_16x16x32_bf16 x3 (hi*hi + hi*lo + lo*hi), operands swapped (weights as the A input) so that a
 //             lane holds 4 consecutive columns of one row; a "unit" = (tower, 16-column fragment) x 64 rows, units are
-//             dealt round-robin to the 4 waves, so the column statistics of a unit never leave its wave
+//             dealt round-robin to the 8 waves, so the column statistics of a unit never leave its wave
 //   stats   : (mean, M2) of the tile per column -> two data-tagged 8-byte granules {tag, value} per column, each ONE relaxed
 //             agent-scope (sc1) store; every workgroup of the segment then merges the partials itself (Chan, tile order): a
 //             thread sweeps the granules of its (column, tile group) item with sc1 loads until every tag matches -- MI355X
@@ -60,7 +60,6 @@ struct TFwdP {
     const float* hc; const float* lin; const float* head_w; int head_ld, D, n_heads, ld_h, h_last;
     float* z; float* prob; float* dz; float* probs_out; int64_t B;
     const float* y; const float* seg_weight; float* loss_part;
-    unsigned* cnt;                                       // [n_level*n_layers][MAX_SEG] arrival counters, zeroed per launch
     unsigned* err;                                       // set to 1 when a bounded spin gives up
     unsigned long long* stamps;                          // diagnostics only (nullable): [n_tiles][64] s_memrealtime at phase ends
     int lds_aimg, lds_actf, lds_gate, max_ngate;         // byte offsets of the LDS regions; widest n_t*n_src

@@ -36,7 +36,7 @@ struct TBwdP {
     const float* glogE; float* dglogE; int ld_ge; const float* glogT; float* dglogT; int ld_gt;
     const float* dz; const float* actLast; const float* head_w; int head_ld, D, n_heads, ld_h, h_last;
     float* dlin; float* head_part; int64_t ld_hp;        // [n_tiles*SUB][ld_hp]: sub-block 0 carries the tile's sums
-    unsigned* cnt; unsigned* err;
+    unsigned* err;
     unsigned long long* stamps;
     int lds_d0, lds_d1, lds_aimg, ldd, ldx, first_buf;   // byte offsets, row strides (floats) of D0/D1 and of the X tile
     RowsP r; ModeP mp;
