@@ -185,6 +185,49 @@ def test_fused_towers_dropin_autograd_path(mode):
         assert d <= 5e-4 * np.abs(ga[n]).max() + 1e-9, (n, d)
 
 
+@pytest.mark.parametrize("seed", [101, 202, 303, 404, 505, 606])
+def test_fused_towers_random_batches(seed):
+    """randomised sweep: batch size, domain mix (empty, one-row, sub-tile and many-tile segments), mask density and dropout
+    drawn per seed; the fused kernels (in-kernel segment hand-offs through data-tagged granules) against the layer-by-layer
+    path on everything the step produces.  Two steps per configuration: the second reuses the hand-off buffers."""
+    import aread_amd
+    from aread_amd import _lib as L
+    rng = np.random.default_rng(seed)
+    dropout = float(rng.choice([0.0, 0.2, 0.5]))
+    spec = spec_full(dropout=dropout)
+    B = int(rng.integers(65, 6000))
+    x = np.stack([rng.integers(0, d, B) for d in spec.field_dims]
+                 + [rng.integers(0, spec.field_dims[0] + 1, B) for _ in range(spec.n_mh_slots)], axis=1).astype(np.int32)
+    p = rng.dirichlet(np.ones(spec.n_domain) * float(rng.choice([0.2, 1.0, 5.0])))
+    dom = rng.choice(spec.n_domain, B, p=p)
+    if seed % 2:
+        dom[dom == 4] = 0                                          # an empty segment
+        dom[0] = 4                                                 # ... turned into a one-row segment (BatchNorm skipped)
+    x[:, spec.domain_idx] = dom
+    y = (rng.random(B) < 0.5).astype(np.float32)
+    masks = [O.random_valid_mask(spec, rng, float(rng.uniform(0.3, 0.9))) for _ in range(spec.n_domain)]
+    model, P = build_model(spec, seed, precision="bf16x3")
+    model.train()
+    model._stats0 = model.bn_stats.clone()
+    model.domain_mask = [[torch.tensor(np.asarray(m), dtype=torch.bool, device="cuda") for m in mk] for mk in masks]
+    md = aread_amd.pack_masks(masks, spec.n_domain, model.edge_num, "cuda")
+    a = _run(model, x, y, md, 0, [])
+    n0 = L.lib().aread_debug_get(b"fused_bwd_calls")
+    b = _run(model, x, y, md, 1, [])
+    b2 = _run(model, x, y, md, 1, [])                              # same inputs, same seed: the fused path is deterministic
+    assert L.lib().aread_debug_get(b"fused_bwd_calls") == n0 + 2
+    assert b["err"] == 0 and b2["err"] == 0
+    for k in ("probs", "gdense", "gtable", "stats"):
+        np.testing.assert_array_equal(b2[k], b[k], err_msg=f"run-to-run {k}")
+    assert abs(a["loss"] - b["loss"]) <= 2e-6 * abs(a["loss"])
+    np.testing.assert_allclose(b["probs"], a["probs"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(b["gate"], a["gate"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(b["stats"], a["stats"], rtol=1e-4, atol=1e-6)
+    for k in ("gdense", "gtable"):
+        d = np.abs(b[k] - a[k]).max()
+        assert d <= 1e-3 * np.abs(a[k]).max() + 1e-9, (k, d)
+
+
 def test_fused_act_bn_backward_matches_two_pass():
     """k_act_bn_bwd (dropout/ReLU backward + BatchNorm backward of an expert layer in one launch, segment sums handed off in the
     kernel; off by default: measured slower) against the two-kernel sequence: identical gradients up to summation order."""
