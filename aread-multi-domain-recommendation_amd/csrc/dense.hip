@@ -236,6 +236,7 @@ extern "C" int aread_debug_phase_times(float* out_ms, int n) {
 
 static int g_fused_mode = -1;        // AREAD_FUSED_TOWERS: 0 = layer-by-layer launches (default: measured faster), 1 = fused tower forward
 extern int g_plan_single;          // plan.hip
+static int g_fused_act_bn = -1;    // AREAD_FUSED_ACT_BN / aread_debug_set("fused_act_bn", v): k_act_bn_bwd for the expert layers (A/B)
 static int g_n_cu = 0;
 static long long g_fused_fwd_calls = 0, g_fused_bwd_calls = 0;   // aread_debug_get: the tests check that the fused kernels really ran
 static int g_tf_stamps = 0;     // aread_debug_set("tf_stamps", 1): phase time stamps of k_tower_fwd into the workspace (tools/tf_stamps.py)
@@ -505,9 +506,13 @@ extern "C" int aread_forward(const aread_model* m, const aread_call* c, const fl
         x.st = x.side;
         LAUNCH(k_mask_prep, dim3(1), dim3(256), mp);
         if (cfg.precision == 1 && fused_towers && !wide_any()) TRY(prepare_wimg(x, 0));   // (the fused tower kernel reads them after the join)
-        if (fused_towers) {
+        if (g_fused_act_bn < 0) { const char* e = getenv("AREAD_FUSED_ACT_BN"); g_fused_act_bn = e ? atoi(e) : 1; }
+        m->ab_tags_clean = false;
+        if (fused_towers || g_fused_act_bn > 0) {
             // hand-off granules of the fused tower kernels (forward AND backward of this step) and the error word: zero tags
-            AR_HIP(hipMemsetAsync(ws + x.w.tf_tags, 0, (size_t)x.w.tf_tags_floats * sizeof(float), x.st));
+            const int64_t n_tag = x.w.tf_tags_floats + (g_fused_act_bn > 0 ? x.w.ab_tags_floats : 0);
+            m->ab_tags_clean = g_fused_act_bn > 0;
+            AR_HIP(hipMemsetAsync(ws + x.w.tf_tags, 0, (size_t)n_tag * sizeof(float), x.st));
             AR_HIP(hipMemsetAsync((unsigned*)(ws + x.w.tf_sync) + AREAD_MAX_LEVEL * AREAD_MAX_LAYER * MAX_SEG, 0, 16 * sizeof(unsigned), x.st));
             m->bwd_tags_clean = true;
         }
@@ -672,7 +677,6 @@ static int flush_reductions(Ctx& x) {
 }
 
 // one MLP layer backward.  d = dL/dAct on entry (in lw.dAct); on exit it holds dL/dH.
-static int g_fused_act_bn = -1;
 static int layer_bwd(Ctx& x, const LayerL& L, const LayerWs& lw, const float* in, float* d_in, int accumulate_d_in,
                      float* grads, int level, int64_t slab_off, hipEvent_t before_dgrad = nullptr) {
     float* ws = x.ws;
@@ -684,15 +688,15 @@ static int layer_bwd(Ctx& x, const LayerL& L, const LayerWs& lw, const float* in
     a.seed = x.c->drop_seed; a.thr = x.thr; a.keep_scale = x.keep_scale; a.r = x.r; a.mp = x.mp;
     // wide layers: both passes in one launch with the segment sums handed off inside the kernel (k_act_bn_bwd); the
     // workgroups that wait for each other sit next to each other in dispatch order, 2 x n_tiles resident ones suffice
-    // MEASURED SLOWER in the step (+40 us: 2432 workgroups that each stall ~5 us in the hand-off against two pure streaming
-    // passes): off by default, kept for A/B (AREAD_FUSED_ACT_BN=1 / aread_debug_set("fused_act_bn", 1)) and covered by a test
+    // With the drain + counter + poll hand-off this was +40 us per step (2432 workgroups stalling ~5 us each); with data-tagged
+    // granules it is -12 us: on by default (AREAD_FUSED_ACT_BN=0 / aread_debug_set("fused_act_bn", 0) for the two-pass path)
     int& fused_ab = g_fused_act_bn;
-    if (fused_ab < 0) { const char* e = getenv("AREAD_FUSED_ACT_BN"); fused_ab = e ? atoi(e) : 0; }
+    if (fused_ab < 0) { const char* e = getenv("AREAD_FUSED_ACT_BN"); fused_ab = e ? atoi(e) : 1; }
     const int n_chunks = cdiv(L.ncols, 64);
-    if (fused_ab && x.w.ab_sync >= 0 && x.w.tf_sync >= 0 && level < 0 && n_chunks <= 16 && L.layer < AREAD_MAX_LAYER && x.n_tiles <= 700) {
+    if (fused_ab && lw.tag_b >= 0 && x.w.tf_sync >= 0 && level < 0 && x.n_tiles <= 700 && x.m->ab_tags_clean) {
         ActBnBwdP q = {};
         q.a = a; q.cpart = ws + lw.cpart;
-        q.cnt = (unsigned*)(ws + x.w.ab_sync) + (size_t)L.layer * 16 * MAX_SEG;
+        q.tags = (tf_u64*)(ws + lw.tag_b);
         q.err = (unsigned*)(ws + x.w.tf_sync) + AREAD_MAX_LEVEL * AREAD_MAX_LAYER * MAX_SEG;
         LAUNCH(k_act_bn_bwd, dim3(x.n_tiles, n_chunks), dim3(256), q);
     } else {
@@ -760,7 +764,7 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     float* ws = x.ws;
     const float* P = x.params;
     phase_mark(x.st, 3);
-    if (g_fused_act_bn < 0) { const char* e = getenv("AREAD_FUSED_ACT_BN"); g_fused_act_bn = e ? atoi(e) : 0; }
+    if (g_fused_act_bn < 0) { const char* e = getenv("AREAD_FUSED_ACT_BN"); g_fused_act_bn = e ? atoi(e) : 1; }
     // Issue order = the order in which a captured graph schedules independent branches (and the order a just-in-time host
     // feeds the queues): the main stream's dependent chain is issued FIRST in every section, the side work behind it waits on
     // events recorded at the right points of the main stream (mark_main / hipStreamWaitEvent).
@@ -854,8 +858,6 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     x.st = x.side;
     AR_HIP(hipStreamWaitEvent(x.side, ev_b0, 0));
     AR_HIP(hipMemsetAsync(grads, 0, (size_t)m->n_params * sizeof(float), x.st));
-    if (x.w.ab_sync >= 0 && g_fused_act_bn > 0)
-        AR_HIP(hipMemsetAsync(ws + x.w.ab_sync, 0, (size_t)AREAD_MAX_LAYER * 16 * MAX_SEG * sizeof(unsigned), x.st));
     // dcn = dz V[:, :D]
     TRY(simple_gemm(x, ws + x.w.dz, m->ld_h, true, P + m->head_w, m->head_ld, false, ws + x.w.dcn, D, nullptr, (int)x.rows, D,
                     m->n_heads, 0, 1));

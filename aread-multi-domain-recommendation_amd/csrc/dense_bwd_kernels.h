@@ -411,27 +411,19 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const BnBwdApplyP p) {
 // ------------------------------------------------------------------------------------------------
 // k_act_bwd + k_bn_bwd_apply in ONE launch for the wide (expert) layers: the dropout / ReLU backward keeps dyhat and xhat of
 // its 64x64 block in registers, hands the block's column sums to the other tiles of the segment inside the kernel (the
-// protocol of tower_fused.h: write-through partial stores into bpart, drain, barrier, one agent-scope counter add, bounded
-// relaxed poll), merges the segment's partials in the order of k_bn_bwd_apply and applies the BatchNorm backward from the
-// registers: d and H are read once instead of twice and one launch boundary disappears (expert L1: 28 + 35 us -> see DESIGN).
+// data-tagged granules of tower_fused.h: one 8-byte {tag, value} store per sum, swept by the merging threads until every tag
+// matches), merges the segment's partials in the order of k_bn_bwd_apply and applies the BatchNorm backward from the
+// registers: d and H are read once instead of twice and one launch boundary disappears (step -12 us; the first version with
+// drain + counter + poll hand-offs was +40 us).
 // Grid (tile, 64-column chunk): the workgroups that wait for each other differ only in the tile index and are dispatched
 // next to each other, so they are co-resident whenever the device holds 2 x n_tiles workgroups (checked by the launcher).
 // ------------------------------------------------------------------------------------------------
 struct ActBnBwdP {
     ActBwdP a;                          // d, H, mean, rstd, gamma, beta, bpart, dropout site ...
     float* cpart;                       // [n_tiles][ncols]
-    unsigned* cnt;                      // [n_chunks][MAX_SEG] arrival counters, zeroed before the launch
+    tf_u64* tags;                       // [n_tiles][ncols][2] data-tagged (sum dyhat, sum dyhat*xhat) granules, zeroed per step
     unsigned* err;
 };
-
-__device__ __forceinline__ void ab_store_sc1(float* p, float a, float b) {
-    union { float f[2]; unsigned long long u; } v;
-    v.f[0] = a; v.f[1] = b;
-    __hip_atomic_store((unsigned long long*)p, v.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float ab_load_sc1(const float* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 __global__ __launch_bounds__(256) void k_act_bn_bwd(const ActBnBwdP q) {
     const ActBwdP& p = q.a;
@@ -495,38 +487,52 @@ __global__ __launch_bounds__(256) void k_act_bn_bwd(const ActBnBwdP q) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) { s1[rg][cq * 4 + i] = a1[i]; s2[rg][cq * 4 + i] = a2[i]; }
     __syncthreads();
+    const int cnt_ = cnt;
+    const bool sync_now = sync_stats;
     if (threadIdx.x < 64 && c0 + threadIdx.x < p.ncols) {
         float t1 = 0.f, t2 = 0.f;
         for (int k = 0; k < 16; ++k) { t1 += s1[k][threadIdx.x]; t2 += s2[k][threadIdx.x]; }
-        ab_store_sc1(p.bpart + ((int64_t)tile * p.ncols + c0 + threadIdx.x) * 2, t1, t2);
+        float* o = p.bpart + ((int64_t)tile * p.ncols + c0 + threadIdx.x) * 2;     // (read later by the bias / gamma / beta reduction)
+        o[0] = t1; o[1] = t2;
+        if (sync_now) tf_put_tagged(q.tags + ((int64_t)tile * p.ncols + c0 + threadIdx.x) * 2, t1, t2);
     }
-    // ---- 2. hand-off: every tile of the segment has published this chunk's partials ----------------------------------
+    // ---- 2. hand-off: sweep the data-tagged granules of the segment's tiles for this chunk's columns ------------------------
     const int ncol_here = (p.ncols - c0 < 64 ? p.ncols - c0 : 64) * 2;
-    if (sync_stats) {
-        const int t0 = p.r.seg_start[seg] / TILE_M, nt = (cnt + TILE_M - 1) / TILE_M;
-        unsigned* ctr = q.cnt + (size_t)blockIdx.y * MAX_SEG + seg;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned spins = 0;
-            while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nt) {
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1u << 22)) { __hip_atomic_store(q.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            }
-        }
-        __syncthreads();
+    if (sync_now) {
+        const int t0 = p.r.seg_start[seg] / TILE_M, nt = (cnt_ + TILE_M - 1) / TILE_M;
         // per-segment sums of this block's 64 columns, the order of k_bn_bwd_apply: two interleaved halves, then combined
         const int v = threadIdx.x & 127, half = threadIdx.x >> 7;
         float acc = 0.f;
         if (v < ncol_here) {
-            const float* src = p.bpart + ((int64_t)t0 * p.ncols + c0) * 2 + v;
+            const tf_u64* src = q.tags + ((int64_t)t0 * p.ncols + c0) * 2 + v;       // granule (column v/2, component v&1) of tile t0
             float b[12];
+            bool have[12];
 #pragma unroll
-            for (int k = 0; k < 12; ++k) { const int t = half + 2 * k; b[k] = t < nt ? ab_load_sc1(src + (int64_t)t * p.ncols * 2) : 0.f; }
+            for (int k = 0; k < 12; ++k) { b[k] = 0.f; have[k] = half + 2 * k >= nt; }
+            for (unsigned spins = 0;;) {
+                bool all = true;
+#pragma unroll
+                for (int k = 0; k < 12; ++k) {
+                    if (!have[k]) {
+                        const tf_u64 x = __hip_atomic_load(src + (int64_t)(half + 2 * k) * p.ncols * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        have[k] = (unsigned)(x >> 32) == TF_TAG;
+                        b[k] = __uint_as_float((unsigned)x);
+                    }
+                    all = all && have[k];
+                }
+                if (all) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 22)) { __hip_atomic_store(q.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
 #pragma unroll
             for (int k = 0; k < 12; ++k) acc += b[k];
-            for (int t = half + 24; t < nt; t += 2) acc += ab_load_sc1(src + (int64_t)t * p.ncols * 2);
+            for (int t = half + 24; t < nt; t += 2) {
+                tf_u64 x;
+                unsigned spins = 0;
+                do { x = __hip_atomic_load(src + (int64_t)t * p.ncols * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                while ((unsigned)(x >> 32) != TF_TAG && ++spins < (1u << 22));
+                acc += __uint_as_float((unsigned)x);
+            }
         }
         s_half[half][v] = acc;
         __syncthreads();

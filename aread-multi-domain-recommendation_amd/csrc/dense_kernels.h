@@ -339,6 +339,23 @@ struct MixLP {
     RowsP r; ModeP mp;
 };
 
+typedef unsigned long long tf_u64;
+// Data-tagged hand-off granules (MI355X guide, Guideline 16 R2): one naturally aligned 8-byte {tag, value} word written by ONE
+// relaxed agent-scope (sc1) store and read by relaxed sc1 loads until the tag matches -- the data is the flag: no drain, no
+// counter, no poll.  A (mean, M2) resp. (sum, sum) pair is two granules.  The tag words are zeroed before every step.
+#define TF_TAG 0x5A17u
+__device__ __forceinline__ void tf_put_tagged(tf_u64* g, float a, float b) {
+    __hip_atomic_store(g, ((tf_u64)TF_TAG << 32) | __float_as_uint(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(g + 1, ((tf_u64)TF_TAG << 32) | __float_as_uint(b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool tf_get_tagged(const tf_u64* g, float& a, float& b) {
+    const tf_u64 x0 = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const tf_u64 x1 = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a = __uint_as_float((unsigned)x0); b = __uint_as_float((unsigned)x1);
+    return (unsigned)(x0 >> 32) == TF_TAG && (unsigned)(x1 >> 32) == TF_TAG;
+}
+
+
 __device__ __forceinline__ void gate_weights(const float* gl, int n_src, const uint8_t* mk, int n_t, int t, int mode,
                                              float* a, float* am, float* ah, float* S) {
     float mx = gl[0];

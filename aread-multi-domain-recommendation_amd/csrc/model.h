@@ -58,6 +58,7 @@ struct aread_model {
     mutable hipStream_t side2 = nullptr;     // second fork-join stream: the row-wise trunk backward beside the expert backward
     mutable hipEvent_t ev[64] = {};
     mutable int n_ev = 0;
+    mutable bool ab_tags_clean = false;    // k_act_bn_bwd's tags were zeroed by the last forward
     mutable bool bwd_tags_clean = false;   // the fused tower backward's hand-off tags were zeroed by the last forward and not used yet
 };
 int model_streams_init(const aread_model* m);
@@ -72,7 +73,7 @@ struct WsLayout {                            // float offsets into the workspace
     int64_t kact, seg_dom;                   // ints: active heads per seg, domain of each seg
     int64_t loss_part, gate_part, rw_part, misc_part;
     int64_t tf_sync;                         // fused tower kernels: arrival counters [MAX_LEVEL*MAX_LAYER][MAX_SEG] x 2 (fwd, bwd) + error words
-    int64_t tf_tags = -1, tf_tags_floats = 0;   // all tag_f / tag_b buffers, contiguous: zeroed by one memset per forward
+    int64_t tf_tags = -1, tf_tags_floats = 0, ab_tags_floats = 0;   // all tag_f / tag_b buffers, contiguous: zeroed by one memset per forward
     int64_t ab_sync = -1;         // k_act_bn_bwd arrival counters (-1: layout without them, e.g. the stand-alone MLP)
     int64_t slab_ex[AREAD_MAX_LAYER], slab_tw[AREAD_MAX_LEVEL][AREAD_MAX_LAYER], slab_head, slab_gate, slab_tgate;
     int64_t total;                           // floats

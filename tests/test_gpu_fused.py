@@ -230,7 +230,7 @@ def test_fused_towers_random_batches(seed):
 
 def test_fused_act_bn_backward_matches_two_pass():
     """k_act_bn_bwd (dropout/ReLU backward + BatchNorm backward of an expert layer in one launch, segment sums handed off in the
-    kernel; off by default: measured slower) against the two-kernel sequence: identical gradients up to summation order."""
+    kernel through data-tagged granules) against the two-kernel sequence: identical gradients up to summation order."""
     import aread_amd
     from aread_amd import _lib as L
     spec = spec_full(dropout=0.2)
@@ -249,7 +249,7 @@ def test_fused_act_bn_backward_matches_two_pass():
             L.check(L.lib().aread_debug_set(b"fused_act_bn", v))
             res.append(_run(model, x, y, md, 1, names))
     finally:
-        L.check(L.lib().aread_debug_set(b"fused_act_bn", 0))
+        L.check(L.lib().aread_debug_set(b"fused_act_bn", 1))
     a, b = res
     assert b["err"] == 0
     for n, _ in names:
