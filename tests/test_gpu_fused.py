@@ -137,7 +137,7 @@ def test_fused_towers_other_geometries(geom):
     np.testing.assert_allclose(b["stats"], a["stats"], rtol=1e-4, atol=1e-6)
     for k in ("gdense", "gtable"):
         d = np.abs(b[k] - a[k]).max()
-        assert d <= 5e-4 * np.abs(a[k]).max() + 1e-9, (k, d)
+        assert d <= 1e-3 * np.abs(a[k]).max() + 1e-9, (k, d)       # 8-wide towers: two split-bf16 roundings apart
 
 
 @pytest.mark.parametrize("mode", ["wo_mask", "domain_with_mask"])
