@@ -35,6 +35,24 @@
 #define TF_MAX_SEG_TILES 256           // tiles of one segment whose row counts are cached in LDS
 #define TF_MERGE_Q 12                  // partial loads in flight per (column, tile group): covers segments of <= 24 tiles at two groups
 
+// the "tower t of this level is active for the tile's segment" bytes as a register bit mask: act[t] in an inner loop was a
+// dependent global load per item (the gate / mix / dot-product phases of both kernels spent most of their time waiting for it)
+struct TFActBits {
+    unsigned b;
+    __device__ __forceinline__ bool operator[](int t) const { return (b >> t) & 1u; }
+};
+__device__ __forceinline__ TFActBits tf_act_bits(const uint8_t* a) {      // a: MAX_TOWER (16) bytes, 16-byte aligned
+    static_assert(MAX_TOWER == 16, "one uint4 load");
+    const uint4 v = *(const uint4*)a;
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+    TFActBits r; r.b = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.b |= (((w[k] >> (8 * j)) & 0xFFu) ? 1u : 0u) << (4 * k + j);
+    return r;
+}
+
 struct TFLayer {
     int n_t, in_w, out_w, ncols;        // towers of the level, per-tower input / output width, n_t*out_w
     int ks, nfr, pk;                    // 32-wide k-steps, 16-wide column fragments per tower, stored 8-wide planes per k-step
@@ -112,7 +130,12 @@ __global__ __launch_bounds__(TF_THREADS) void k_tower_fwd(const TFwdP p) {
     const int t0 = p.r.seg_start[seg] / TILE_M, nt = (cnt + TILE_M - 1) / TILE_M;
     const int64_t row0 = (int64_t)tile * TILE_M;
     const bool bn = cnt > 1;
-    const uint8_t* masks = p.mp.masks ? p.mp.masks + (size_t)p.mp.seg_dom[seg] * p.mp.edge_count : nullptr;
+    // the segment's edge-mask bytes in LDS: the gate phases read them per (row, tower, source) item
+    __shared__ uint8_t s_mask[512];
+    const uint8_t* gmasks = p.mp.masks ? p.mp.masks + (size_t)p.mp.seg_dom[seg] * p.mp.edge_count : nullptr;
+    const bool mask_lds = gmasks && p.mp.edge_count <= 512;
+    if (mask_lds) for (int i = threadIdx.x; i < p.mp.edge_count; i += TF_THREADS) s_mask[i] = gmasks[i];
+    const uint8_t* masks = mask_lds ? s_mask : gmasks;
 
     // dropout keys of this lane's four rows (m = mi*16 + fr), rows-per-tile of the segment's tiles: read once
     uint32_t dkey[4] = {0u, 0u, 0u, 0u};
@@ -137,7 +160,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_tower_fwd(const TFwdP p) {
     int gates_ready = -1;
     auto compute_gates = [&](int l) {
         const int n_t = p.L[l][0].n_t;
-        const uint8_t* act = active_level(p.mp, l) + seg * MAX_TOWER;
+        const TFActBits act = tf_act_bits(active_level(p.mp, l) + seg * MAX_TOWER);
         const int n_src = l == 0 ? p.n_exp : p.n_t[l - 1];
         const int ngate = n_t * n_src;
         for (int it = tid; it < TILE_M * n_t; it += TF_THREADS) {
@@ -211,7 +234,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_tower_fwd(const TFwdP p) {
     for (int l = 0; l < p.n_level; ++l) {
         const TFLayer& L0 = p.L[l][0];
         const int n_t = L0.n_t, in_w = L0.in_w, ks0 = L0.ks;
-        const uint8_t* act = active_level(p.mp, l) + seg * MAX_TOWER;
+        const TFActBits act = tf_act_bits(active_level(p.mp, l) + seg * MAX_TOWER);
         // ---------------- level input: gate mix of the previous level (or of the experts) -> In[l], A image ----------------
         {
             const int n_src = l == 0 ? p.n_exp : p.n_t[l - 1];
@@ -582,7 +605,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_tower_fwd(const TFwdP p) {
     // ---------------- heads: z = cn.v[:D] + lin + act.v[D:], sigmoid, bagging BCE and its gradient ------------------------
     {
         const int LL = p.n_level - 1;
-        const uint8_t* act = active_level(p.mp, LL) + seg * MAX_TOWER;
+        const TFActBits act = tf_act_bits(active_level(p.mp, LL) + seg * MAX_TOWER);
         const float cntf = (float)cnt, kact = (float)p.mp.kact[seg];
         const float wseg = p.seg_weight ? p.seg_weight[seg] : 1.f;
         float loss = 0.f;

@@ -67,7 +67,12 @@ __global__ __launch_bounds__(TF_THREADS) void k_tower_bwd(const TBwdP p) {
     const int64_t row0 = (int64_t)tile * TILE_M;
     const bool bn = cnt > 1;
     const float inv_n = 1.0f / (float)cnt;
-    const uint8_t* masks = p.mp.masks ? p.mp.masks + (size_t)p.mp.seg_dom[seg] * p.mp.edge_count : nullptr;
+    // the segment's edge-mask bytes and tower-active bytes in LDS: the gate phases read them per (row, tower, source) item
+    __shared__ uint8_t s_mask[512];
+    const uint8_t* gmasks = p.mp.masks ? p.mp.masks + (size_t)p.mp.seg_dom[seg] * p.mp.edge_count : nullptr;
+    const bool mask_lds = gmasks && p.mp.edge_count <= 512;
+    if (mask_lds) for (int i = threadIdx.x; i < p.mp.edge_count; i += TF_THREADS) s_mask[i] = gmasks[i];
+    const uint8_t* masks = mask_lds ? s_mask : gmasks;
     const int ldd = p.ldd;
     const bool drop = p.train && p.thr;
     if (tid < TILE_M) s_key[tid] = drop ? drop_row_key(p.seed, (uint32_t)p.r.row_sample[row0 + tid]) : 0u;
@@ -87,7 +92,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_tower_bwd(const TBwdP p) {
     {
         const int LL = p.n_level - 1;
         const int ncols = p.n_heads * p.h_last;
-        const uint8_t* act = active_level(p.mp, LL) + seg * MAX_TOWER;
+        const TFActBits act = tf_act_bits(active_level(p.mp, LL) + seg * MAX_TOWER);
         // dz tile -> LDS; thread = (column quad, row group): dAct rows and the dv_tail partial (shuffle-reduced) together
         float* s_dz = s_scr;                                // [64][n_heads]
         for (int it = tid; it < TILE_M * p.n_heads; it += TF_THREADS) {
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_tower_bwd(const TBwdP p) {
 
     for (int l = p.n_level - 1; l >= 0; --l) {
         const int n_t = p.n_t[l];
-        const uint8_t* act = active_level(p.mp, l) + seg * MAX_TOWER;
+        const TFActBits act = tf_act_bits(active_level(p.mp, l) + seg * MAX_TOWER);
         for (int j = p.n_layers - 1; j >= 0; --j) {
             const TBLayer& L = p.L[l][j];
             const int ncols = L.ncols, out_w = L.out_w, in_w = L.in_w;
