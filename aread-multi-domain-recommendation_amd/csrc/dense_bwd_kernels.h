@@ -1034,10 +1034,12 @@ __global__ __launch_bounds__(256) void k_l2_dense(const float* w, const float* c
     float acc = 0.f;
     const int64_t n4 = ((((uintptr_t)w | (uintptr_t)coef | (uintptr_t)grads) & 15) == 0) ? n >> 2 : 0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        // all three loads in flight together (the gradient load used to wait for the coefficient test: two dependent round trips
+        // per iteration on the serial tail of the step)
         const float4 c = ((const float4*)coef)[i], v = ((const float4*)w)[i];
+        float4 g = grads ? ((const float4*)grads)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         acc += c.x * v.x * v.x; acc += c.y * v.y * v.y; acc += c.z * v.z * v.z; acc += c.w * v.w * v.w;
         if (grads && (c.x != 0.f || c.y != 0.f || c.z != 0.f || c.w != 0.f)) {
-            float4 g = ((float4*)grads)[i];
             g.x += 2.0f * c.x * v.x; g.y += 2.0f * c.y * v.y; g.z += 2.0f * c.z * v.z; g.w += 2.0f * c.w * v.w;
             ((float4*)grads)[i] = g;
         }
