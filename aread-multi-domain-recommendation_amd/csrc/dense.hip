@@ -501,6 +501,7 @@ extern "C" int aread_forward(const aread_model* m, const aread_call* c, const fl
     // 1.-3. (side stream, joined before the MMoE mix: the expert layers need none of it) mask tables, row-wise trunk,
     // gate logits, cross-network part of the heads
     AR_HIP(hipStreamWaitEvent(x.side, ev_f0, 0));
+    hipEvent_t ev_towers = nullptr;
     {
         const hipStream_t main_st = x.st;
         x.st = x.side;
@@ -517,11 +518,6 @@ extern "C" int aread_forward(const aread_model* m, const aread_call* c, const fl
             m->bwd_tags_clean = true;
         }
         if (c->probs) AR_HIP(hipMemsetAsync(c->probs, 0, (size_t)m->n_heads * c->B * sizeof(float), x.st));
-        if (c->train && cfg.precision == 1) {
-            TRY(transpose_weights(x));
-            if (wide_any()) TRY(prepare_wimg(x, 1));
-            else if (tower_fused_bwd_ok(x)) TRY(prepare_wimg(x, 1, true));   // dgrad images of the tower layers
-        }
         RowwiseP rw = {};
         rw.e = e_in; rw.cn = ws + x.w.cn; rw.lin = ws + x.w.lin; rw.xw = ws + x.w.xw; rw.q = ws + x.w.q; rw.grp = ws + x.w.grp;
         rw.lin_w = P + m->lin_w; rw.lin_b = P + m->lin_b; rw.cn_w = P + m->cn_w; rw.cn_b = P + m->cn_b;
@@ -535,10 +531,22 @@ extern "C" int aread_forward(const aread_model* m, const aread_call* c, const fl
                             (int)x.rows, m->gate_rows, 2 * E, 0, 1));
         TRY(simple_gemm(x, ws + x.w.cn, D, true, P + m->head_w, m->head_ld, true, ws + x.w.hc, m->ld_h, nullptr, (int)x.rows,
                         m->n_heads, D, 0, 1));
+        // everything the tower pyramid needs is queued: the main stream joins HERE; what only the backward reads (transposed
+        // weights, dgrad weight images) follows on the side stream beside the tower kernel and is awaited by aread_backward
+        ev_towers = x.m->ev[x.ev_next++ % (x.m->n_ev - 1)];
+        AR_HIP(hipEventRecord(ev_towers, x.side));
+        m->prep_pending = false;
+        if (c->train && cfg.precision == 1) {
+            TRY(transpose_weights(x));
+            if (wide_any()) TRY(prepare_wimg(x, 1));
+            else if (tower_fused_bwd_ok(x)) TRY(prepare_wimg(x, 1, true));   // dgrad images of the tower layers
+            AR_HIP(hipEventRecord(m->ev_prep, x.side));
+            m->prep_pending = true;
+        }
         x.st = main_st;
     }
     // 5.-7. MMoE mix, tower pyramid, heads + fused bagging loss: one launch when the configuration allows it
-    TRY(join_side(x));
+    AR_HIP(hipStreamWaitEvent(x.st, ev_towers, 0));
     const bool want_gates = c->gate_stats != nullptr && m->gate_rows > 0;
     const bool have_loss = c->y && c->loss_out;
     if (fused_towers) {
@@ -774,6 +782,10 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
         return AREAD_OK;
     };
     const hipStream_t main_st = x.st;
+    if (m->prep_pending) {                                   // transposed weights / dgrad images of this step's forward (side stream)
+        AR_HIP(hipStreamWaitEvent(x.st, m->ev_prep, 0));
+        m->prep_pending = false;
+    }
     // 1. dz
     HeadsP hp = {};
     hp.prob = ws + x.w.prob; hp.dz = ws + x.w.dz; hp.n_heads = m->n_heads; hp.ld_h = m->ld_h; hp.B = c->B;

@@ -155,6 +155,7 @@ int model_streams_init(const aread_model* m) {
     AR_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
     AR_HIP(hipStreamCreateWithFlags(&m->side2, hipStreamNonBlocking));
     for (int i = 0; i < 64; ++i) AR_HIP(hipEventCreateWithFlags(&m->ev[i], hipEventDisableTiming));
+    AR_HIP(hipEventCreateWithFlags(&m->ev_prep, hipEventDisableTiming));
     m->n_ev = 64;
     return AREAD_OK;
 }
@@ -163,6 +164,7 @@ extern "C" void aread_model_destroy(aread_model* m) {
     if (!m) return;
     if (m->side) {
         for (int i = 0; i < m->n_ev; ++i) (void)hipEventDestroy(m->ev[i]);
+        if (m->ev_prep) (void)hipEventDestroy(m->ev_prep);
         (void)hipStreamDestroy(m->side);
         if (m->side2) (void)hipStreamDestroy(m->side2);
     }

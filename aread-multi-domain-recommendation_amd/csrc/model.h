@@ -57,6 +57,8 @@ struct aread_model {
     mutable hipStream_t side = nullptr;
     mutable hipStream_t side2 = nullptr;     // second fork-join stream: the row-wise trunk backward beside the expert backward
     mutable hipEvent_t ev[64] = {};
+    mutable hipEvent_t ev_prep = nullptr;    // forward: the backward-only preparations (transposed weights, dgrad images) are done on the side stream
+    mutable bool prep_pending = false;
     mutable int n_ev = 0;
     mutable bool ab_tags_clean = false;    // k_act_bn_bwd's tags were zeroed by the last forward
     mutable bool bwd_tags_clean = false;   // the fused tower backward's hand-off tags were zeroed by the last forward and not used yet
