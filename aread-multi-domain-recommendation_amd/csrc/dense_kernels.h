@@ -48,13 +48,18 @@ struct MaskPrepP {
 };
 
 __global__ __launch_bounds__(256) void k_mask_prep(const MaskPrepP p) {
+    // the tables are built in LDS and written out once: every phase used to re-read the previous phase's bytes from global
+    // memory (this single-workgroup kernel heads the side chain the tower kernel waits for)
+    __shared__ uint8_t s_active[AREAD_MAX_LEVEL * MAX_SEG * MAX_TOWER];
+    __shared__ int s_dom[MAX_SEG], s_n0[MAX_SEG];
     const int tid = threadIdx.x;
     int n_tot = 0;
     for (int l = 0; l < p.n_level; ++l) n_tot += p.n_tower[l];
-    for (int i = tid; i < AREAD_MAX_LEVEL * MAX_SEG * MAX_TOWER; i += 256) p.active[i] = 0;
+    for (int i = tid; i < AREAD_MAX_LEVEL * MAX_SEG * MAX_TOWER; i += 256) s_active[i] = 0;
     for (int s = tid; s < MAX_SEG; s += 256) {
         int dom = p.n_seg == 1 ? p.domain : s;
         dom = dom < 0 ? 0 : (dom >= p.n_domain ? p.n_domain - 1 : dom);
+        s_dom[s] = dom;
         p.seg_dom[s] = dom;
     }
     __syncthreads();
@@ -65,22 +70,25 @@ __global__ __launch_bounds__(256) void k_mask_prep(const MaskPrepP p) {
         while (t >= p.n_tower[l]) { t -= p.n_tower[l]; ++l; }
         int a = 1;
         if (p.mode == 0) {
-            const uint8_t* mk = p.masks + (size_t)p.seg_dom[s] * p.edge_count + p.mask_off[l];
-            const int n_src = l == 0 ? 1 : p.n_tower[l - 1];
+            const uint8_t* mk = p.masks + (size_t)s_dom[s] * p.edge_count + p.mask_off[l];
+            const int n_src = l == 0 ? 1 : p.n_tower[l - 1], nt = p.n_tower[l];
             a = 0;
-            for (int src = 0; src < n_src; ++src) a |= mk[src * p.n_tower[l] + t] ? 1 : 0;
+#pragma unroll 4
+            for (int src = 0; src < n_src; ++src) a |= mk[src * nt + t] ? 1 : 0;
         }
-        p.active[((size_t)l * MAX_SEG + s) * MAX_TOWER + t] = (uint8_t)a;
+        s_active[((size_t)l * MAX_SEG + s) * MAX_TOWER + t] = (uint8_t)a;
     }
     __syncthreads();
+    for (int i = tid; i < AREAD_MAX_LEVEL * MAX_SEG * MAX_TOWER / 4; i += 256) ((uint32_t*)p.active)[i] = ((const uint32_t*)s_active)[i];
     for (int s = tid; s < MAX_SEG; s += 256) {
         int k = 0, n0 = 0;
         if (s < p.n_seg) {
-            for (int t = 0; t < p.n_tower[0]; ++t) n0 += p.active[(size_t)s * MAX_TOWER + t];
-            for (int t = 0; t < p.n_tower[p.n_level - 1]; ++t) k += p.active[((size_t)(p.n_level - 1) * MAX_SEG + s) * MAX_TOWER + t];
+            for (int t = 0; t < p.n_tower[0]; ++t) n0 += s_active[(size_t)s * MAX_TOWER + t];
+            for (int t = 0; t < p.n_tower[p.n_level - 1]; ++t) k += s_active[((size_t)(p.n_level - 1) * MAX_SEG + s) * MAX_TOWER + t];
         }
         p.kact[s] = k;
         p.n0act[s] = n0;
+        s_n0[s] = n0;
     }
     __syncthreads();
     // group embedding of each segment: mean of the rows of the active level-0 towers (0 in wo_mask)
@@ -89,8 +97,8 @@ __global__ __launch_bounds__(256) void k_mask_prep(const MaskPrepP p) {
         float acc = 0.f;
         if (p.mode == 0) {
             for (int t = 0; t < p.n_tower[0]; ++t)
-                if (p.active[(size_t)s * MAX_TOWER + t]) acc += p.group_emb[t * p.E + c];
-            const int n0 = p.n0act[s];
+                if (s_active[(size_t)s * MAX_TOWER + t]) acc += p.group_emb[t * p.E + c];
+            const int n0 = s_n0[s];
             if (n0 > 1) acc = acc / (float)n0;
         }
         p.grp[i] = acc;
