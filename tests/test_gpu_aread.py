@@ -213,7 +213,10 @@ def test_split_bf16_mode_within_tolerance(which):
     x = torch.from_numpy(G["multi_rand/x"]).cuda()
     y = torch.from_numpy(G["multi_rand/y"].astype(np.float32)).cuda()
     bufs = model.make_step_buffers(x.shape[0], multi_domain=True)
+    n0 = _fused_calls()
     loss = model.train_step(x, y, bufs)
+    if which == "full":        # the configuration the fused tower kernels take (tiny: in_dim % 8 != 0 -> layer-by-layer path)
+        assert _fused_calls() == (n0[0] + 1, n0[1] + 1), "k_tower_fwd / k_tower_bwd did not produce these numbers"
     ref = G["multi_rand/probs"]
     ok = ~np.isnan(ref)
     got = bufs["probs"].cpu().numpy()
@@ -225,7 +228,16 @@ def test_split_bf16_mode_within_tolerance(which):
     # ... and norm-wise per tensor (measured: median 5e-5, 90th percentile 1e-3, worst tower tensor 5e-3; the exact-fp32
     # mode sits at 3e-6 on the same fixtures, test_fp32_mode_gradients_norm_wise below)
     e = _rel_l2(U.rel_l2_vs_golden(G, "multi_rand/grad", all_grads(model)))
-    assert np.median(e) <= 2e-4 and np.quantile(e, 0.9) <= 3e-3 and e.max() <= 2e-2, (np.median(e), np.quantile(e, 0.9), e.max())
+    print(f"[bf16x3 vs golden, {which}] gradient rel-L2 per tensor: median {np.median(e):.2e} p90 {np.quantile(e, 0.9):.2e} max {e.max():.2e}")
+    # bounds = 2x the measured triple (r3d: full 4.7e-5 / 1.0e-3 / 5.1e-3, tiny 2.8e-5 / 5.8e-5 / 1.3e-4)
+    assert np.median(e) <= 1e-4 and np.quantile(e, 0.9) <= 2e-3 and e.max() <= 1e-2, (np.median(e), np.quantile(e, 0.9), e.max())
+
+
+def _fused_calls():
+    """(k_tower_fwd launches, k_tower_bwd launches) so far: the oracle comparisons on the timed configuration assert that the
+    fused kernels -- not the layer-by-layer fallback -- produced the numbers they check"""
+    from aread_amd import _lib as L
+    return (L.lib().aread_debug_get(b"fused_fwd_calls"), L.lib().aread_debug_get(b"fused_bwd_calls"))
 
 
 def _pre_bn_bias(name):
@@ -260,7 +272,8 @@ def test_baseline_size_proportional_gradients_vs_fp64_oracle():
     removed (11 samples: BatchNorm over 1-3 rows is ill-conditioned in any precision): EVERY parameter gradient, norm-wise,
     against an fp64 run of the oracle.  The fp32 oracle itself is 3e-6 (median) / 5e-4 (90th percentile) / 2e-3 (worst) away
     from fp64 -- the per-domain BatchNorm backward amplifies rounding by ~1e3 -- so the bounds are: exact-fp32 mode the
-    oracle's own distance, split-bf16 mode that times the ~1e3 larger product error (measured median 2e-3, p90 7e-3)."""
+    oracle's own distance, split-bf16 mode that times the ~1e3 larger product error.  Measured (r3d, printed by the test):
+    f32 median 3.2e-6 / p90 3.5e-4 / max 1.0e-3, split-bf16 2.4e-3 / 7.4e-3 / 4.1e-2; the bounds are 2x those."""
     import aread_amd
     from tools import synth
     spec = O.amazon_spec(dropout=0.0)
@@ -275,13 +288,16 @@ def test_baseline_size_proportional_gradients_vs_fp64_oracle():
     P = O.init_params(spec, 123)
     P64 = {k: (v.double() if v.is_floating_point() else v) for k, v in P.items()}
     r64 = O.step(P64, spec, x, y.astype(np.float64), masks)
-    for precision, med, p90, worst in (("f32", 3e-5, 3e-3, 1e-2), ("bf16x3", 1e-2, 3e-2, 0.15)):
+    for precision, med, p90, worst in (("f32", 1e-5, 7e-4, 2e-3), ("bf16x3", 5e-3, 1.5e-2, 8e-2)):     # <= 2x the measured triples below
         model, _ = U.build_model(spec, 123, precision=precision)
         model.train()
         md = aread_amd.pack_masks(masks, spec.n_domain, model.edge_num, "cuda")
         model.domain_mask = [tmask(m) for m in masks]
         bufs = model.make_step_buffers(x.shape[0])
+        n0 = _fused_calls()
         loss = model.train_step(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), bufs, masks_dev=md)
+        if precision == "bf16x3":
+            assert _fused_calls() == (n0[0] + 1, n0[1] + 1), "the timed configuration must run k_tower_fwd / k_tower_bwd"
         assert abs(float(loss) - r64["loss"]) <= 5e-5 * abs(r64["loss"]), precision
         g = all_grads(model)
         e = {}
@@ -291,6 +307,8 @@ def test_baseline_size_proportional_gradients_vs_fp64_oracle():
                 e[n] = float(np.linalg.norm(g[n].astype(np.float64) - ref) / np.linalg.norm(ref))
         v = _rel_l2(e)
         assert len(v) > 200
+        print(f"[B=8192 proportional vs fp64 oracle, {precision}] gradient rel-L2 per tensor: median {np.median(v):.2e} "
+              f"p90 {np.quantile(v, 0.9):.2e} max {v.max():.2e} ({max((n for n in e if not _pre_bn_bias(n)), key=e.get)})")
         assert np.median(v) <= med and np.quantile(v, 0.9) <= p90 and v.max() <= worst, (precision, np.median(v), np.quantile(v, 0.9), v.max())
         assert e["embedding.embedding_dict.weight"] <= (1e-4 if precision == "f32" else 5e-3), (precision, e["embedding.embedding_dict.weight"])
         del model, bufs
@@ -410,6 +428,9 @@ def test_baseline_size_step_vs_oracle_both_precisions(domain_dist):
     torch.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
     P = O.init_params(spec, 123)
     r = O.step(P, spec, x, y, masks, want_grads=(domain_dist == "uniform"))
+    # yardstick for the ill-conditioned few-row domains: an fp64 run of the oracle (forward only)
+    P64 = {k: (v.double() if v.is_floating_point() else v) for k, v in P.items()}
+    r64 = O.step(P64, spec, x, y.astype(np.float64), masks, want_grads=False)
     ok = ~np.isnan(r["probs"])
     refl = r["logits"][ok]
     cnt = np.bincount(x[:, spec.domain_idx], minlength=spec.n_domain)
@@ -418,18 +439,40 @@ def test_baseline_size_step_vs_oracle_both_precisions(domain_dist):
     assert sel.sum() > 0.99 * ok.sum()
     # gradient spot checks at this size are sanity bounds (25 per-domain BatchNorm backward passes with cancellation:
     # the fp32 oracle itself is ~1 % of max away from fp64); strict gradient parity is pinned by the golden tests
-    for precision, gtol in (("f32", 3e-2), ("bf16x3", 6e-2)):
+    for precision, gtol, kfac in (("f32", 3e-2, 10.0), ("bf16x3", 6e-2, 150.0)):
         model, _ = U.build_model(spec, 123, precision=precision)
         model.train()
         md = aread_amd.pack_masks(masks, spec.n_domain, model.edge_num, "cuda")
         model.domain_mask = [tmask(m) for m in masks]
         bufs = model.make_step_buffers(8192)
+        n0 = _fused_calls()
         loss = model.train_step(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), bufs, masks_dev=md)
+        if precision == "bf16x3":
+            assert _fused_calls() == (n0[0] + 1, n0[1] + 1), "the timed configuration must run k_tower_fwd / k_tower_bwd"
         got = bufs["probs"].cpu().numpy()
         assert (got[~ok] == 0).all()
         dl = np.abs(logits_of(got.astype(np.float64)) - r["logits"].astype(np.float64))
         assert dl[sel].max() <= 1e-4 * max(np.abs(refl).max(), 1.0), (precision, dl[sel].max())
-        assert np.isfinite(got[ok]).all() and np.abs(got[ok & ~big] - r["probs"][ok & ~big]).max(initial=0.0) < 0.2
+        assert np.isfinite(got[ok]).all()
+        small = ok & ~big
+        if small.any():
+            # domains of 1-7 rows (BatchNorm over 2-3 rows: x_hat = +-1, rstd up to 1/sqrt(eps)): the fp64 oracle is the
+            # yardstick -- the HIP probabilities may be kfac times as far from it as the fp32 oracle is (f32: the same
+            # arithmetic in another summation order; split-bf16: 4e-6 per product against fp32's 6e-8, ~70x)
+            e_ref = np.abs(r["probs"][small].astype(np.float64) - r64["probs"][small].astype(np.float64))
+            e_hip = np.abs(got[small].astype(np.float64) - r64["probs"][small].astype(np.float64))
+            q = lambda v: (float(np.median(v)), float(np.quantile(v, 0.9)), float(v.max()))
+            print(f"[B=8192 {domain_dist}, {precision}] few-row domains ({int(small.sum())} probabilities): |hip - fp64| median/p90/max "
+                  f"{q(e_hip)}, |oracle32 - fp64| {q(e_ref)}; logits of the other domains: max |d| {dl[sel].max():.2e}")
+            # measured (r3e): f32 median 3.0e-7 / p90 1.0e-5 / max 1.8e-2 against the fp32 oracle's own 1.8e-7 / 1.4e-6 / 4.0e-4;
+            # split-bf16 median 7.0e-6 / p90 1.5e-2 / max 4.7e-2.  The typical (median) error obeys the yardstick; the tail does
+            # not in ANY implementation: two nearly equal rows give x_hat = 158 * (x1 - x2) per layer (eps = 1e-5), nine
+            # BatchNorm layers deep, so a 1e-7 difference in summation order decides single probabilities -- bounded absolutely,
+            # at half the previous slack
+            assert q(e_hip)[0] <= kfac * q(e_ref)[0] + 1e-6, (precision, q(e_hip), q(e_ref))
+            if precision == "f32":
+                assert q(e_hip)[1] <= kfac * q(e_ref)[1] + 1e-6, (precision, q(e_hip), q(e_ref))
+            assert q(e_hip)[2] <= 0.1, (precision, q(e_hip))
         bags = bufs["loss"].cpu().numpy()[1:]
         for d_, b_ in r["bag_by_domain"].items():
             if cnt[d_] >= 8:
