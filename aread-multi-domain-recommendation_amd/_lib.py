@@ -33,6 +33,7 @@ _SIGS = {
     "aread_embed_bwd_sort": (C.c_int, [i32p, C.c_int64, C.c_int, i32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, i32p, vp, vp]),
     "aread_embed_bwd_reduce": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.c_int, f32p, f32p, vp, vp]),
+    "aread_embed_bwd_reduce2": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, vp, vp]),
     "aread_route_ws_bytes": (C.c_int64, [C.c_int64, C.c_int]),
     "aread_route_build": (C.c_int, [i32p, C.c_int64, C.c_int, i32p, C.c_int64, C.c_int, vp, i32p, i32p, i32p, C.c_int, vp]),
     "aread_adam_step": (C.c_int, [f32p, f32p, f32p, f32p, C.c_int64, vp, vp, vp]),

@@ -46,7 +46,8 @@ class Call(C.Structure):
                 ("nbt", C.c_void_p), ("ws", C.c_void_p), ("probs", C.c_void_p), ("gate_stats", C.c_void_p),
                 ("y", C.c_void_p), ("seg_weight", C.c_void_p), ("loss_out", C.c_void_p), ("async_tail", C.c_int32),
                 ("l2_table", C.c_void_p), ("l2_n", C.c_int64), ("l2_coef", C.c_float), ("l2_workgroups", C.c_int32),
-                ("l2_grad", C.c_void_p), ("l2_partial", C.c_void_p), ("l2_reg_out", C.c_void_p), ("l2_dense_coef", C.c_void_p)]
+                ("l2_grad", C.c_void_p), ("l2_partial", C.c_void_p), ("l2_reg_out", C.c_void_p), ("l2_dense_coef", C.c_void_p),
+                ("grads_init", C.c_int32), ("init_grads", C.c_void_p), ("init_reg_out", C.c_void_p), ("de_rw", C.c_void_p)]
 
 
 for _n, _r, _a in [
@@ -61,6 +62,9 @@ for _n, _r, _a in [
     ("aread_model_gate_rows", C.c_int, [C.c_void_p]),
     ("aread_model_workspace_bytes", C.c_int64, [C.c_void_p, C.c_int64, C.c_int]),
     ("aread_model_l2_coef", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("aread_prepare", C.c_int, [C.c_void_p, C.POINTER(Call), C.c_void_p]),
+    ("aread_l2_dense_init", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("aread_step_total", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("aread_forward", C.c_int, [C.c_void_p, C.POINTER(Call), C.c_void_p, C.c_void_p]),
     ("aread_backward", C.c_int, [C.c_void_p, C.POINTER(Call), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("aread_join", C.c_int, [C.c_void_p, C.c_void_p]),
@@ -89,6 +93,12 @@ def pack_masks(masks, n_domain, edge_count, device):
 class _CallState:
     """Everything one forward leaves behind for its backward (buffers are owned here)."""
     __slots__ = ("plan", "e", "ws", "call", "keep", "probs", "x")
+
+
+class PreparedBatch:
+    """The ids-only stage of a step (AREAD.prepare_batch): row plan + the embedding backward's index sort of one batch,
+    computed on the model's prefetch stream while the previous step runs; `ready` is recorded behind both."""
+    __slots__ = ("x", "plan", "sort_ws", "ready", "n_seg")
 
 
 class _AreadFn(torch.autograd.Function):
@@ -282,9 +292,15 @@ class AREAD(HempMixin, nn.Module):
         self.l2_pass_workgroups = int(os.environ.get("AREAD_L2_WG", "0"))   # width of the table L2 sweep inside the fused step
         self.l2_pass_early = os.environ.get("AREAD_L2_EARLY", "0") == "1"    # A/B: the sweep right after the row plan (round 1)
         self.l2_pass_in_backward = os.environ.get("AREAD_L2_IN_BWD", "1") == "1"   # default: issued by aread_backward beside the tower backward
-        self.l2_dense_in_backward = os.environ.get("AREAD_L2_DENSE_IN_BWD", "0") == "1"   # A/B only
         self.sort_early = os.environ.get("AREAD_SORT_EARLY", "0") == "1"                  # A/B: index sort issued before the forward (graph replay: +10 us)
+        self.prepare_early = os.environ.get("AREAD_PREPARE_EARLY", "1") == "1"            # aread_prepare ahead of the row plan (A/B: 0 = inside aread_forward)
+        self.l2_dense_first = os.environ.get("AREAD_L2_DENSE_FIRST", "1") == "1"          # dense L2 terms at the head of train_step (A/B: 0 = at its tail)
+        self._dense_l2_done_first = False
+        self.split_de = os.environ.get("AREAD_SPLIT_DE", "1") == "1"                      # row-wise share of dL/de in its own buffer (A/B: 0 = accumulated into de)
+        self._train_step_owner = False
+        self._de_split = False
         self.drop_seed = None          # set to an int to pin the dropout stream (tests)
+        self._marks = None             # tools/step_anatomy.py: list collecting (name, event) at the step's host-level boundaries
         self._register_state_dict_hook(AREAD._sd_hook)
         self._register_load_state_dict_pre_hook(self._load_hook)
 
@@ -456,9 +472,10 @@ class AREAD(HempMixin, nn.Module):
         return pack_masks(masks, self.n_domain, self._edge_count, device)
 
     def _run(self, x, mode_id, n_seg, domain, masks_dev, want_gates, y=None, seg_weight=None, loss_out=None,
-             ws=None, plan=None, probs=None, e=None, e_ready=False, async_fwd=False):
+             ws=None, plan=None, probs=None, e=None, e_ready=False, async_fwd=False, pre=None):
         """plan + embedding + dense forward.  Returns a _CallState (buffers owned by it).
-        e_ready: `e` already holds the pooled embedding in plan order (row-sharded table, dist.ShardedTableStep)."""
+        e_ready: `e` already holds the pooled embedding in plan order (row-sharded table, dist.ShardedTableStep).
+        pre: the tuple _make_call returned (the fused step builds the call first and hands it to aread_prepare)."""
         L.require_device(x, self.dense, self.embedding.embedding_dict.weight)
         L.require(x, torch.int32, "x")
         lib = L.lib()
@@ -475,12 +492,24 @@ class AREAD(HempMixin, nn.Module):
                                         table.shape[0], emb.embed_dim, emb.one_hot_field_num, emb.multi_hot_field_num,
                                         emb.seq_maxlen, emb._pool, L.ptr(st.plan.row_sample), st.plan.max_rows,
                                         L.ptr(st.e), None, L.stream()))
+        if pre is None:
+            pre = self._make_call(x.device, B, mode_id, n_seg, domain, masks_dev, want_gates, y, seg_weight, loss_out, ws, probs,
+                                  async_fwd)
+        call, st.ws, st.probs, gate, st.keep = pre
+        call.plan = L.ptr(st.plan.buf)
+        st.call = call
+        L.check(lib.aread_forward(self._handle, C.byref(call), L.ptr(st.e), L.stream()))
+        return st, gate
+
+    def _make_call(self, device, B, mode_id, n_seg, domain, masks_dev, want_gates, y=None, seg_weight=None, loss_out=None,
+                   ws=None, probs=None, async_fwd=False):
+        """The aread_call of one forward (everything but the row plan) and the buffers it points to."""
+        lib = L.lib()
         if ws is None:
             nbytes = lib.aread_model_workspace_bytes(self._handle, B, n_seg)
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-        st.ws = ws
-        st.probs = probs if probs is not None else torch.empty((self.n_heads, B), dtype=torch.float32, device=x.device)
-        gate = torch.zeros((n_seg, max(self._gate_rows, 1)), dtype=torch.float32, device=x.device) if want_gates else None
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        probs = probs if probs is not None else torch.empty((self.n_heads, B), dtype=torch.float32, device=device)
+        gate = torch.zeros((n_seg, max(self._gate_rows, 1)), dtype=torch.float32, device=device) if want_gates else None
         train = self.training
         if train and self.dropout > 0:
             self._drop_calls += 1
@@ -489,15 +518,12 @@ class AREAD(HempMixin, nn.Module):
         call.update_running, call.domain = int(train), int(domain if domain is not None else 0)
         call.drop_seed = ((self.drop_seed_base + self._drop_calls * 0x9E3779B1) if self.drop_seed is None
                           else int(self.drop_seed)) & 0xFFFFFFFF
-        call.plan, call.masks = L.ptr(st.plan.buf), L.ptr(masks_dev)
+        call.masks = L.ptr(masks_dev)
         call.params, call.stats, call.nbt = L.ptr(self.dense), L.ptr(self.bn_stats), L.ptr(self.bn_nbt)
-        call.ws, call.probs, call.gate_stats = L.ptr(ws), L.ptr(st.probs), L.ptr(gate)
+        call.ws, call.probs, call.gate_stats = L.ptr(ws), L.ptr(probs), L.ptr(gate)
         call.y, call.seg_weight, call.loss_out = L.ptr(y), L.ptr(seg_weight), L.ptr(loss_out)
         call.async_tail = 2 if async_fwd else 0          # fused step: loss / running stats finish on the library's side stream
-        st.call = call
-        st.keep = (masks_dev, gate, y, seg_weight, loss_out)
-        L.check(lib.aread_forward(self._handle, C.byref(call), L.ptr(st.e), L.stream()))
-        return st, gate
+        return call, ws, probs, gate, (masks_dev, gate, y, seg_weight, loss_out)
 
     def _record_gates(self, gate_row, d, memory_gate_value, tmp_memory_gate_value):
         """Side outputs of aread.py:187-200,275-295 from the kernel's [gate_rows] vector."""
@@ -598,14 +624,58 @@ class AREAD(HempMixin, nn.Module):
             ws=torch.empty(lib.aread_model_workspace_bytes(self._handle, B, n_seg), dtype=torch.uint8, device=device),
             e=torch.empty((int(lay.max_rows), self.embed_output_dim), dtype=torch.float32, device=device),
             de=torch.empty((int(lay.max_rows), self.embed_output_dim), dtype=torch.float32, device=device),
+            de_rw=torch.empty((int(lay.max_rows), self.embed_output_dim), dtype=torch.float32, device=device),
             probs=torch.empty((self.n_heads, B), dtype=torch.float32, device=device),
             loss=torch.zeros(1 + n_seg, dtype=torch.float32, device=device),
             reg=torch.zeros(257, dtype=torch.float32, device=device),
+            reg_dense=torch.zeros(257, dtype=torch.float32, device=device),
             total=torch.zeros(1, dtype=torch.float32, device=device),
             gdense=torch.zeros_like(self.dense),
             gtable=torch.empty_like(self.embedding.embedding_dict.weight.data) if with_table_grad else None,
         )
         return bufs
+
+    def prepare_batch(self, x, multi_domain=True, sort=True, reuse=None):
+        """Input-pipeline stage of the fused step: everything of a batch that depends only on its ids -- the row plan
+        (run.py:310-353's per-domain loaders become one bucketing pass) and the index sort of the embedding backward -- on the
+        model's prefetch stream, forked from the current stream HERE, so that it runs while the previous step computes.
+        Returns a PreparedBatch for train_step(..., prepared=).  reuse: a PreparedBatch of the same shape whose buffers are
+        overwritten (two of them alternate in a training loop)."""
+        L.require_device(x)
+        n_seg = self.n_domain if multi_domain else 1
+        emb = self.embedding
+        pb = PreparedBatch()
+        pb.x, pb.n_seg = x, n_seg
+        need = emb.bwd_ws_bytes(x) if sort else 0
+        buf = reuse.plan.buf if reuse is not None else None
+        pb.sort_ws = None
+        if sort:
+            pb.sort_ws = reuse.sort_ws if (reuse is not None and reuse.sort_ws is not None and reuse.sort_ws.numel() >= need) \
+                else torch.empty(need, dtype=torch.uint8, device=x.device)
+        if buf is None:                      # allocated on the caller's stream (the step that consumes it runs there)
+            lay = L.PlanLayout()
+            L.check(L.lib().aread_plan_layout_get(x.shape[0], n_seg, lay))
+            buf = torch.empty(int(lay.words), dtype=torch.int32, device=x.device)
+        main = torch.cuda.current_stream()
+        key = "pf:" + str(x.device)
+        if key not in self._streams:
+            self._streams[key] = torch.cuda.Stream(device=x.device)
+        pf = self._streams[key]
+        pf.wait_stream(main)
+        with torch.cuda.stream(pf):
+            pb.plan = RowPlan(x, self.domain_idx if n_seg > 1 else -1, n_seg, buf=buf)
+            if sort:
+                emb.sort_lookups(x, pb.plan.sample_row, ws=pb.sort_ws)
+            pb.ready = torch.cuda.Event()
+            pb.ready.record(pf)
+        return pb
+
+    def _mark(self, name):
+        """diagnostics only (tools/step_anatomy.py): a timing event on the current stream when a collector is installed"""
+        if self._marks is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._marks.append((name, ev))
 
     def _side_stream(self, device):
         key = str(device)
@@ -615,7 +685,7 @@ class AREAD(HempMixin, nn.Module):
 
     def step_local(self, x, y, bufs, masks_dev=None, domain_i=None, seg_weight=None, with_reg=True,
                    with_dense_l2=True, want_gates=False, presort=True, plan=None, e_ready=False, l2_target=None,
-                   table_pass=True):
+                   table_pass=True, prepared=None, dense_l2_first=False):
         """Rank-local part of the step: row plan, gather, dense forward + bagging BCE + backward on the current
         stream; concurrently on a side stream (fork-join, capturable): the table L2 pass
         (bufs['gtable'] = 2*l2*W, bufs['reg'] = l2 terms) and, with presort, the index sort of the embedding
@@ -635,8 +705,29 @@ class AREAD(HempMixin, nn.Module):
         # Host issue order matters (eager launches): row plan, then the table L2 pass on the side stream, then the main
         # stream gets its whole forward; only then the index sort (which needs the row plan, not the forward) is queued
         # on the side stream, so the main stream never waits for the host.
+        self._mark("step start")
+        # the call first: its plan-independent preparation (mask tables, weight images, tag memsets, transposed weights) forks
+        # onto the library's side stream NOW, ahead of the row plan and the gather
+        pre = self._make_call(x.device, x.shape[0], 0, n_seg, domain_i, masks_dev, want_gates, y, seg_weight, bufs["loss"],
+                              bufs["ws"], bufs["probs"], True)
+        dense_first = bool(dense_l2_first and with_reg and with_dense_l2 and self.prepare_early)
+        if dense_first:
+            # dense half of get_regularization_loss at the HEAD of the step, on the library's side stream (aread_prepare): gdense
+            # starts as 2*coef*w and the backward adds every gradient onto it (bitwise the same sums as adding the L2 term last)
+            pre[0].l2_dense_coef = L.ptr(self._l2_coef(self.dense.device))
+            pre[0].init_grads, pre[0].init_reg_out = L.ptr(bufs["gdense"]), L.ptr(bufs["reg_dense"])
+        if self.prepare_early:
+            L.check(lib.aread_prepare(self._handle, C.byref(pre[0]), L.stream()))
+        pre[0].init_grads = None
+        if prepared is not None:
+            if prepared.n_seg != n_seg or prepared.x.data_ptr() != x.data_ptr():
+                raise ValueError("train_step: the PreparedBatch belongs to another batch / segment layout")
+            main.wait_event(prepared.ready)
+            plan = prepared.plan
+            presort = False                            # the index sort is part of the prepared batch
         if plan is None:                               # first on the main stream: everything else waits for it, and it is
             plan = RowPlan(x, self.domain_idx if n_seg > 1 else -1, n_seg)     # latency-bound (slow next to the HBM-saturating L2 pass)
+        self._mark("row plan")
         # The table L2 pass (356 MB of HBM traffic, needed only by the embedding reduction at the very end) goes on the side
         # stream BEHIND the forward (AREAD_L2_EARLY=1: right after the row plan, as in round 1): next to the latency-bound head
         # of the step (gather, first GEMM) it cost those kernels 2-3x their isolated time.
@@ -664,9 +755,8 @@ class AREAD(HempMixin, nn.Module):
         elif presort:
             plan_ready = torch.cuda.Event()
             plan_ready.record(main)
-        st, gate = self._run(x, 0, n_seg, domain_i, masks_dev, want_gates, y=y, seg_weight=seg_weight,
-                             loss_out=bufs["loss"], ws=bufs["ws"], probs=bufs["probs"], e=bufs["e"], plan=plan,
-                             e_ready=e_ready, async_fwd=True)
+        st, gate = self._run(x, 0, n_seg, domain_i, masks_dev, want_gates, e=bufs["e"], plan=plan, e_ready=e_ready, pre=pre)
+        self._mark("gather + forward")
         in_bwd = self.l2_pass_in_backward and not self.l2_pass_early and table_pass and with_reg
         if not self.l2_pass_early and not in_bwd:
             l2_pass()
@@ -679,15 +769,21 @@ class AREAD(HempMixin, nn.Module):
             st.call.l2_table, st.call.l2_n, st.call.l2_coef = L.ptr(table), table.numel(), self.l2_reg_embedding
             st.call.l2_workgroups = self.l2_pass_workgroups or 256   # one workgroup per CU: leaves room for the tower kernel's
             st.call.l2_grad, st.call.l2_partial, st.call.l2_reg_out = L.ptr(gtable), L.ptr(part), L.ptr(bufs["reg"])
-            if with_dense_l2 and self.l2_dense_in_backward:   # (measured 40 us SLOWER: the extra cross-stream hop costs more than the two kernels)
-                st.call.l2_dense_coef = L.ptr(self._l2_coef(self.dense.device))
+        st.call.grads_init = 1 if dense_first else 0      # gdense = 2*coef*w was queued on the library's side stream by aread_prepare
+        split_de = self.split_de and self._train_step_owner and bufs.get("de_rw") is not None    # only train_step adds the two shares (other callers read bufs["de"] whole)
+        st.call.de_rw = L.ptr(bufs["de_rw"]) if split_de else None
+        self._de_split = bool(split_de)
         L.check(lib.aread_backward(self._handle, C.byref(st.call), L.ptr(st.e), None, L.ptr(bufs["gdense"]),
                                    L.ptr(bufs["de"]), L.stream()))
         st.call.async_tail = 0
+        st.call.grads_init = 0
+        st.call.de_rw = None
         st.call.l2_table = None
         st.call.l2_dense_coef = None
+        self._mark("backward (main stream: to the last dgrad)")
         main.wait_stream(side)          # table L2 pass + index sort
-        self._pending_dense_l2 = bool(with_reg and with_dense_l2) and not (in_bwd and self.l2_dense_in_backward)
+        self._pending_dense_l2 = bool(with_reg and with_dense_l2) and not dense_first
+        self._dense_l2_done_first = dense_first
         self._last = (st, gate)
         return st
 
@@ -708,16 +804,29 @@ class AREAD(HempMixin, nn.Module):
         self.embedding.scatter_grad(x, de, gtable, sample_row)
 
     def train_step(self, x, y, bufs, masks_dev=None, domain_i=None, seg_weight=None, with_reg=True, set_grads=True,
-                   want_gates=False):
+                   want_gates=False, prepared=None):
         """forward + bagging BCE + L2 + backward to every parameter gradient, no host sync, no allocation
         besides the row plan (run.py:668-680 without the optimizer).  y: float32 [B] on the device.
-        Returns the device scalar loss = sum_d w_d*bag_d + reg."""
-        st = self.step_local(x, y, bufs, masks_dev, domain_i, seg_weight, with_reg, True, want_gates, presort=True)
+        prepared: the batch's PreparedBatch (prepare_batch(x), issued one step ahead): row plan and index sort are then not
+        part of this step's dependency chain.  Returns the device scalar loss = sum_d w_d*bag_d + reg."""
+        self._train_step_owner = True       # (step_local may keep the row-wise share of dL/de apart: reduce_sorted below adds the two)
+        try:
+            st = self.step_local(x, y, bufs, masks_dev, domain_i, seg_weight, with_reg, True, want_gates, presort=True,
+                                 prepared=prepared, dense_l2_first=self.l2_dense_first)
+        finally:
+            self._train_step_owner = False
         # tail, all on the main stream (every cross-stream hop costs more than the few small kernels it could overlap): the
         # segmented reduction into the table gradient, then the join with the library's parameter-gradient reductions
         # (long finished by then) and the dense L2 term
-        self.embedding.reduce_sorted(x, bufs["de"], bufs["gtable"])
-        if self._pending_dense_l2:      # join + dense L2 terms + total = loss + reg in one launch
+        self._mark("join index sort")
+        self.embedding.reduce_sorted(x, bufs["de"], bufs["gtable"], ws=prepared.sort_ws if prepared is not None else None,
+                                     dout2=bufs["de_rw"] if self._de_split else None)
+        self._mark("table-gradient segmented reduction")
+        if self._dense_l2_done_first:   # join + the step's two final scalars (the dense L2 terms were formed at the head)
+            L.check(L.lib().aread_join(self._handle, L.stream()))
+            L.check(L.lib().aread_step_total(L.ptr(bufs["loss"]), L.ptr(bufs["reg_dense"]), L.ptr(bufs["reg"]), L.ptr(bufs["total"]),
+                                             L.stream()))
+        elif self._pending_dense_l2:    # join + dense L2 terms + total = loss + reg in one launch
             L.check(L.lib().aread_join(self._handle, L.stream()))
             L.check(L.lib().aread_l2_dense_total(L.ptr(self.dense), L.ptr(self._l2_coef(self.dense.device)), self.dense.numel(),
                                                  L.ptr(bufs["gdense"]), L.ptr(bufs["reg"]), 1, L.ptr(bufs["loss"]),
@@ -726,6 +835,7 @@ class AREAD(HempMixin, nn.Module):
         else:
             self.step_finish(bufs)
             torch.add(bufs["loss"][:1], bufs["reg"][:1], out=bufs["total"])
+        self._mark("join parameter gradients + dense L2 + total")
         if set_grads:
             for p in self.dense_params:
                 p.grad = None

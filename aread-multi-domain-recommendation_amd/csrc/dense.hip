@@ -471,6 +471,129 @@ static int tower_fused_bwd(Ctx& x, float* grads) {
     return AREAD_OK;
 }
 
+// ---- the forward's tail on the side stream: loss value from the per-tile partials, running statistics in domain order ----
+static int forward_tail(Ctx& x, bool fused_towers) {
+    const aread_model* m = x.m;
+    const aread_call* c = x.c;
+    const aread_model_cfg& cfg = m->cfg;
+    float* ws = x.ws;
+    if (c->y && c->loss_out) {
+        hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(64), 0, x.side, ws + x.w.loss_part, c->seg_weight, c->loss_out, x.r,
+                           fused_towers ? (const unsigned*)(ws + x.w.tf_sync) + AREAD_MAX_LEVEL * AREAD_MAX_LAYER * MAX_SEG : nullptr);
+        AR_LAUNCH_CHECK();
+    }
+    if (c->train && c->update_running) {
+        BnRunAllP all = {};
+        int max_cols = 0;
+        auto add = [&](const LayerL& L, const LayerWs& lw, int level) {
+            BnRunP& p = all.L[all.n_layers++];
+            p.mean = ws + lw.mean; p.var = ws + lw.var; p.rmean = c->stats + L.rmean; p.rvar = c->stats + L.rvar;
+            p.nbt = c->nbt + L.nbt0; p.ncols = L.ncols; p.h = L.out_dim; p.level = level;
+            if (L.ncols > max_cols) max_cols = L.ncols;
+        };
+        for (int j = 0; j < m->experts.n_layers; ++j) add(m->experts.L[j], x.w.ex[j], -1);
+        for (int l = 0; l < cfg.n_level; ++l)
+            for (int j = 0; j < m->towers[l].n_layers; ++j) add(m->towers[l].L[j], x.w.tw[l][j], l);
+        all.r = x.r; all.mp = x.mp;
+        // off the critical path: the statistics buffers are not touched again before the next forward
+        hipLaunchKernelGGL(k_bn_running, dim3(cdiv(max_cols, 256), all.n_layers), dim3(256), 0, x.side, all);
+        AR_LAUNCH_CHECK();
+    }
+    return AREAD_OK;
+}
+
+// ---- the part of the forward's side work that depends on the parameters, the masks and the call's scalars only (not on
+// the row plan, not on the embedding output): mask tables + group embedding, pre-tiled weight images, hand-off tag memsets,
+// the probs memset; in training also what only the backward reads (transposed weights, dgrad weight images, behind
+// ev_prep).  Launched on x.st (the side stream).  aread_prepare() issues it at the very start of a step -- before the row
+// plan and the gather -- so that only the row-wise trunk and the three gate / head GEMMs remain between the gather and the
+// tower kernel on the side stream; without aread_prepare, aread_forward runs it in place.
+static int forward_prep(Ctx& x, bool with_plan_independent_tail) {
+    const aread_model* m = x.m;
+    const aread_call* c = x.c;
+    const aread_model_cfg& cfg = m->cfg;
+    float* ws = x.ws;
+    const float* P = x.params;
+    MaskPrepP mp = {};
+    mp.masks = x.mp.masks; mp.n_seg = c->n_seg; mp.domain = c->domain; mp.mode = c->mode; mp.n_level = cfg.n_level;
+    mp.n_domain = cfg.n_domain; mp.edge_count = m->edge_count; mp.E = m->E;
+    for (int l = 0; l < cfg.n_level; ++l) mp.n_tower[l] = cfg.n_tower[l];
+    for (int l = 0; l <= cfg.n_level; ++l) mp.mask_off[l] = m->mask_off[l];
+    mp.group_emb = P + m->group_emb;
+    mp.active = (uint8_t*)(ws + x.w.active); mp.kact = (int32_t*)(ws + x.w.kact); mp.n0act = mp.kact + MAX_SEG;
+    mp.seg_dom = (int32_t*)(ws + x.w.seg_dom); mp.grp = ws + x.w.grp;
+    const bool fused_towers = tower_fused_ok(x);
+    LAUNCH(k_mask_prep, dim3(1), dim3(256), mp);
+    if (cfg.precision == 1 && fused_towers && !wide_any()) TRY(prepare_wimg(x, 0));   // (the fused tower kernel reads them after the join)
+    if (g_fused_act_bn < 0) { const char* e = getenv("AREAD_FUSED_ACT_BN"); g_fused_act_bn = e ? atoi(e) : 1; }
+    m->ab_tags_clean = false;
+    if (fused_towers || g_fused_act_bn > 0) {
+        // hand-off granules of the fused tower kernels (forward AND backward of this step) and the error word: zero tags
+        const int64_t n_tag = x.w.tf_tags_floats + (g_fused_act_bn > 0 ? x.w.ab_tags_floats : 0);
+        m->ab_tags_clean = g_fused_act_bn > 0;
+        AR_HIP(hipMemsetAsync(ws + x.w.tf_tags, 0, (size_t)n_tag * sizeof(float), x.st));
+        AR_HIP(hipMemsetAsync((unsigned*)(ws + x.w.tf_sync) + AREAD_MAX_LEVEL * AREAD_MAX_LAYER * MAX_SEG, 0, 16 * sizeof(unsigned), x.st));
+        m->bwd_tags_clean = true;
+    }
+    if (c->probs) AR_HIP(hipMemsetAsync(c->probs, 0, (size_t)m->n_heads * c->B * sizeof(float), x.st));
+    if (with_plan_independent_tail) {
+        // (only the backward reads these; aread_backward waits for ev_prep)
+        m->prep_pending = false;
+        if (c->train && cfg.precision == 1) {
+            TRY(transpose_weights(x));
+            if (wide_any()) TRY(prepare_wimg(x, 1));
+            else if (tower_fused_bwd_ok(x)) TRY(prepare_wimg(x, 1, true));   // dgrad images of the tower layers
+            AR_HIP(hipEventRecord(m->ev_prep, x.st));
+            m->prep_pending = true;
+        }
+    }
+    return AREAD_OK;
+}
+
+// make_ctx without a row plan (aread_prepare runs before the plan exists)
+static int make_ctx_noplan(const aread_model* m, const aread_call* c, void* stream, Ctx* x) {
+    AR_CHECK_ARG(m && c, "aread: null model/call");
+    AR_CHECK_ARG(c->B > 0 && c->params && c->ws, "aread: null params/ws or B <= 0");
+    AR_CHECK_ARG(c->n_seg == 1 || c->n_seg == m->cfg.n_domain, "aread: n_seg=%d must be 1 or n_domain=%d", c->n_seg, m->cfg.n_domain);
+    AR_CHECK_ARG(c->mode == 0 || c->mode == 1, "aread: mode=%d", c->mode);
+    AR_CHECK_ARG(c->mode == 1 || c->masks, "aread: masked mode needs masks");
+    AR_CHECK_ARG(c->mode == 0 || c->n_seg == 1, "aread: wo_mask runs as one segment");
+    AR_CHECK_ARG(((uintptr_t)c->ws & 255) == 0 && ((uintptr_t)c->params & 15) == 0, "aread: ws must be 256-byte, params 16-byte aligned");
+    aread_call tmp = *c;
+    static const int32_t dummy_plan[4] = {0, 0, 0, 0};
+    tmp.plan = dummy_plan;                                   // never dereferenced: the kernels of forward_prep take no RowsP
+    TRY0(make_ctx(m, &tmp, stream, x));
+    x->c = c;
+    x->r = RowsP{};
+    return AREAD_OK;
+}
+
+extern "C" int aread_prepare(const aread_model* m, const aread_call* c, void* stream) {
+    Ctx x;
+    TRY(make_ctx_noplan(m, c, stream, &x));
+    AR_CHECK_ARG(!m->is_mlp, "aread_prepare: not an AREAD handle");
+    // the side stream forks HERE (everything queued on `stream` so far -- the previous step included -- precedes it)
+    TRY(fork_side(x));
+    const hipStream_t main_st = x.st;
+    x.st = x.side;
+    const int rc = forward_prep(x, true);
+    // (everything above precedes the event the forward's main stream waits for before the tower kernel: the backward needs no
+    // separate wait for the transposed weights / dgrad images)
+    m->prep_pending = false;
+    if (rc == AREAD_OK && c->init_grads) {
+        // dense half of get_regularization_loss at the HEAD of the step: grads = 2*coef*w, reg = sum coef*w^2 (k_l2_dense, init
+        // mode); the backward's reductions run on this stream and its successor (side2 waits on it) and ADD onto the buffer
+        if (!(c->l2_dense_coef && c->init_reg_out)) { x.st = main_st; AR_CHECK_ARG(false, "aread_prepare: init_grads needs l2_dense_coef and init_reg_out"); }
+        hipLaunchKernelGGL(k_l2_dense, dim3(256), dim3(256), 0, x.side, x.params, c->l2_dense_coef, m->n_params, c->init_grads,
+                           c->init_reg_out + 1, c->init_reg_out, 0, (const float*)nullptr, (float*)nullptr, 1);
+        if (hipGetLastError() != hipSuccess) { x.st = main_st; AR_CHECK_ARG(false, "aread_prepare: k_l2_dense launch failed"); }
+    }
+    x.st = main_st;
+    if (rc != AREAD_OK) return rc;
+    m->fwd_prepared = c->ws;                                 // consumed by the next aread_forward on this workspace
+    return AREAD_OK;
+}
+
 extern "C" int aread_forward(const aread_model* m, const aread_call* c, const float* e_in, void* stream) {
     Ctx x;
     TRY(make_ctx(m, c, stream, &x));
@@ -480,15 +603,8 @@ extern "C" int aread_forward(const aread_model* m, const aread_call* c, const fl
     const int D = m->D, E = m->E;
     float* ws = x.ws;
     const float* P = x.params;
-    // 1. mask tables + group embedding
-    MaskPrepP mp = {};
-    mp.masks = x.mp.masks; mp.n_seg = c->n_seg; mp.domain = c->domain; mp.mode = c->mode; mp.n_level = cfg.n_level;
-    mp.n_domain = cfg.n_domain; mp.edge_count = m->edge_count; mp.E = E;
-    for (int l = 0; l < cfg.n_level; ++l) mp.n_tower[l] = cfg.n_tower[l];
-    for (int l = 0; l <= cfg.n_level; ++l) mp.mask_off[l] = m->mask_off[l];
-    mp.group_emb = P + m->group_emb;
-    mp.active = (uint8_t*)(ws + x.w.active); mp.kact = (int32_t*)(ws + x.w.kact); mp.n0act = mp.kact + MAX_SEG;
-    mp.seg_dom = (int32_t*)(ws + x.w.seg_dom); mp.grp = ws + x.w.grp;
+    const bool prepared = m->fwd_prepared == c->ws && c->ws != nullptr;      // aread_prepare already queued the plan-independent side work
+    m->fwd_prepared = nullptr;
     const bool fused_towers = tower_fused_ok(x);
     if (cfg.precision == 1 && wide_any()) TRY(prepare_wimg(x, 0));    // forward weight images: the wide expert GEMMs need them first
     // 4. experts FIRST on the main stream (issue order = the order a captured graph schedules independent branches): the
@@ -505,19 +621,7 @@ extern "C" int aread_forward(const aread_model* m, const aread_call* c, const fl
     {
         const hipStream_t main_st = x.st;
         x.st = x.side;
-        LAUNCH(k_mask_prep, dim3(1), dim3(256), mp);
-        if (cfg.precision == 1 && fused_towers && !wide_any()) TRY(prepare_wimg(x, 0));   // (the fused tower kernel reads them after the join)
-        if (g_fused_act_bn < 0) { const char* e = getenv("AREAD_FUSED_ACT_BN"); g_fused_act_bn = e ? atoi(e) : 1; }
-        m->ab_tags_clean = false;
-        if (fused_towers || g_fused_act_bn > 0) {
-            // hand-off granules of the fused tower kernels (forward AND backward of this step) and the error word: zero tags
-            const int64_t n_tag = x.w.tf_tags_floats + (g_fused_act_bn > 0 ? x.w.ab_tags_floats : 0);
-            m->ab_tags_clean = g_fused_act_bn > 0;
-            AR_HIP(hipMemsetAsync(ws + x.w.tf_tags, 0, (size_t)n_tag * sizeof(float), x.st));
-            AR_HIP(hipMemsetAsync((unsigned*)(ws + x.w.tf_sync) + AREAD_MAX_LEVEL * AREAD_MAX_LAYER * MAX_SEG, 0, 16 * sizeof(unsigned), x.st));
-            m->bwd_tags_clean = true;
-        }
-        if (c->probs) AR_HIP(hipMemsetAsync(c->probs, 0, (size_t)m->n_heads * c->B * sizeof(float), x.st));
+        if (!prepared) TRY(forward_prep(x, false));
         RowwiseP rw = {};
         rw.e = e_in; rw.cn = ws + x.w.cn; rw.lin = ws + x.w.lin; rw.xw = ws + x.w.xw; rw.q = ws + x.w.q; rw.grp = ws + x.w.grp;
         rw.lin_w = P + m->lin_w; rw.lin_b = P + m->lin_b; rw.cn_w = P + m->cn_w; rw.cn_b = P + m->cn_b;
@@ -535,13 +639,15 @@ extern "C" int aread_forward(const aread_model* m, const aread_call* c, const fl
         // weights, dgrad weight images) follows on the side stream beside the tower kernel and is awaited by aread_backward
         ev_towers = x.m->ev[x.ev_next++ % (x.m->n_ev - 1)];
         AR_HIP(hipEventRecord(ev_towers, x.side));
-        m->prep_pending = false;
-        if (c->train && cfg.precision == 1) {
-            TRY(transpose_weights(x));
-            if (wide_any()) TRY(prepare_wimg(x, 1));
-            else if (tower_fused_bwd_ok(x)) TRY(prepare_wimg(x, 1, true));   // dgrad images of the tower layers
-            AR_HIP(hipEventRecord(m->ev_prep, x.side));
-            m->prep_pending = true;
+        if (!prepared) {
+            m->prep_pending = false;
+            if (c->train && cfg.precision == 1) {
+                TRY(transpose_weights(x));
+                if (wide_any()) TRY(prepare_wimg(x, 1));
+                else if (tower_fused_bwd_ok(x)) TRY(prepare_wimg(x, 1, true));   // dgrad images of the tower layers
+                AR_HIP(hipEventRecord(m->ev_prep, x.side));
+                m->prep_pending = true;
+            }
         }
         x.st = main_st;
     }
@@ -584,36 +690,20 @@ extern "C" int aread_forward(const aread_model* m, const aread_call* c, const fl
     LAUNCH(k_heads_fwd, dim3(x.n_tiles * SUB), dim3(256), hp);
     }
     phase_mark(x.st, 2);
-    HeadsP hp = {};
-    hp.loss_part = have_loss ? ws + x.w.loss_part : nullptr;
-    const bool side_tail = hp.loss_part || (c->train && c->update_running);
-    if (side_tail) TRY(fork_side(x));
-    if (hp.loss_part) {
-        hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(64), 0, x.side, ws + x.w.loss_part, c->seg_weight, c->loss_out, x.r,
-                           fused_towers ? (const unsigned*)(ws + x.w.tf_sync) + AREAD_MAX_LEVEL * AREAD_MAX_LAYER * MAX_SEG : nullptr);
-        AR_LAUNCH_CHECK();
+    const bool side_tail = have_loss || (c->train && c->update_running);
+    m->fwd_tail_deferred = false;
+    if (side_tail) {
+        if (c->async_tail & 2) {
+            // fused step: aread_backward follows on this stream with the same call.  The forward's tail (loss value, running
+            // statistics: nothing on the main stream reads them) is queued by the backward on the side stream behind its own
+            // first fork -- one event record less on the main stream's dependent chain (each costs it 3-9 us).
+            m->fwd_tail_deferred = true;
+        } else {
+            TRY(fork_side(x));
+            TRY(forward_tail(x, fused_towers));
+            TRY(join_side(x));
+        }
     }
-    // 8. running statistics, in domain order
-    if (c->train && c->update_running) {
-        BnRunAllP all = {};
-        int max_cols = 0;
-        auto add = [&](const LayerL& L, const LayerWs& lw, int level) {
-            BnRunP& p = all.L[all.n_layers++];
-            p.mean = ws + lw.mean; p.var = ws + lw.var; p.rmean = c->stats + L.rmean; p.rvar = c->stats + L.rvar;
-            p.nbt = c->nbt + L.nbt0; p.ncols = L.ncols; p.h = L.out_dim; p.level = level;
-            if (L.ncols > max_cols) max_cols = L.ncols;
-        };
-        for (int j = 0; j < m->experts.n_layers; ++j) add(m->experts.L[j], x.w.ex[j], -1);
-        for (int l = 0; l < cfg.n_level; ++l)
-            for (int j = 0; j < m->towers[l].n_layers; ++j) add(m->towers[l].L[j], x.w.tw[l][j], l);
-        all.r = x.r; all.mp = x.mp;
-        // off the critical path: the statistics buffers are not touched again before the next forward
-        hipLaunchKernelGGL(k_bn_running, dim3(cdiv(max_cols, 256), all.n_layers), dim3(256), 0, x.side, all);
-        AR_LAUNCH_CHECK();
-    }
-    // async_tail bit 1: loss_out / running statistics finish on the side stream (fused step: the backward that follows
-    // does not read them and queues its own side-stream work behind them; aread_join() covers both)
-    if (side_tail && !(c->async_tail & 2)) TRY(join_side(x));
     return AREAD_OK;
 }
 
@@ -645,7 +735,12 @@ static int wgrad(Ctx& x, const float* dY, int64_t ld_dy, int64_t dy_gs, const fl
 
 // fork once, then every pending weight-gradient GEMM on the side stream.  split-bf16 mode: the row-contiguous operands go
 // through the transposing LDS reads (k_gemm_bf3_rc), 3 bf16 MFMA products instead of the fp32 MFMA.
+// split-bf16 mode: ONE launch for the whole range (k_gemm_bf3_rc_multi) -- as separate launches the dozen tower / gate / head
+// weight gradients were a ~190 us serial chain of 8-22 us kernels on the side stream and the step's tail waited for it
+static int g_wgrad_multi = -1;     // AREAD_WGRAD_MULTI=0: one launch per weight gradient (A/B)
 static int flush_wgrads_range(Ctx& x, int lo, int hi) {
+    if (g_wgrad_multi < 0) { const char* e = getenv("AREAD_WGRAD_MULTI"); g_wgrad_multi = e ? atoi(e) : 1; }
+    if (x.m->cfg.precision == 1 && g_wgrad_multi) return launch_gemm_bf3_rc_multi(x.pend + lo, hi - lo, x.side);
     for (int i = lo; i < hi; ++i) {
         if (x.m->cfg.precision == 1) TRY(launch_gemm_bf3_rc(x.pend[i], x.side));
         else TRY(launch_gemm(x.pend[i], false, false, x.side));
@@ -654,10 +749,7 @@ static int flush_wgrads_range(Ctx& x, int lo, int hi) {
 }
 static int flush_wgrads(Ctx& x, bool fork) {
     if (fork) TRY(fork_side(x));
-    for (int i = 0; i < x.n_pend; ++i) {
-        if (x.m->cfg.precision == 1) TRY(launch_gemm_bf3_rc(x.pend[i], x.side));
-        else TRY(launch_gemm(x.pend[i], false, false, x.side));
-    }
+    TRY(flush_wgrads_range(x, 0, x.n_pend));
     x.n_pend = 0;
     return AREAD_OK;
 }
@@ -686,7 +778,7 @@ static int flush_reductions(Ctx& x) {
 
 // one MLP layer backward.  d = dL/dAct on entry (in lw.dAct); on exit it holds dL/dH.
 static int layer_bwd(Ctx& x, const LayerL& L, const LayerWs& lw, const float* in, float* d_in, int accumulate_d_in,
-                     float* grads, int level, int64_t slab_off, hipEvent_t before_dgrad = nullptr) {
+                     float* grads, int level, int64_t slab_off, hipEvent_t before_dgrad = nullptr, bool fork_after_act = false) {
     float* ws = x.ws;
     float* d = ws + lw.dAct;
     ActBwdP a = {};
@@ -720,6 +812,7 @@ static int layer_bwd(Ctx& x, const LayerL& L, const LayerWs& lw, const float* in
     bo.ncols = L.ncols; bo.h = L.out_dim; bo.level = level;
     const bool shared = L.in_gs == 0 && L.G > 1;
     const uint8_t* act = (level >= 0 && L.G > 1) ? level_active(x, level) : nullptr;
+    if (fork_after_act) TRY(fork_side(x));         // dH is final: the side stream's weight gradients may start beside the dgrad
     // dgrad: d_in = dH W
     if (d_in && before_dgrad) AR_HIP(hipStreamWaitEvent(x.st, before_dgrad, 0));   // (whoever initialises d_in for an accumulating dgrad)
     if (d_in) {
@@ -766,16 +859,23 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     TRY(make_ctx(m, c, stream, &x));
     AR_CHECK_ARG(e_in && grads && de_out, "aread_backward: null e_in/grads/de_out");
     AR_CHECK_ARG(dprobs || c->y, "aread_backward: need dprobs or labels");
-    AR_CHECK_ARG(((uintptr_t)grads & 15) == 0 && ((uintptr_t)de_out & 15) == 0, "aread_backward: alignment");
+    AR_CHECK_ARG(((uintptr_t)grads & 15) == 0 && ((uintptr_t)de_out & 15) == 0 && ((uintptr_t)c->de_rw & 15) == 0, "aread_backward: alignment");
     const aread_model_cfg& cfg = m->cfg;
     const int D = m->D, E = m->E, LL = cfg.n_level - 1;
     float* ws = x.ws;
     const float* P = x.params;
     phase_mark(x.st, 3);
     if (g_fused_act_bn < 0) { const char* e = getenv("AREAD_FUSED_ACT_BN"); g_fused_act_bn = e ? atoi(e) : 1; }
+    // Stream plan.  Every event record / cross-stream wait on the MAIN stream costs its dependent chain 3-9 us
+    // (profiles/r02_event_cost.txt, r03_step_anatomy.txt), so the main stream records exactly two events here (after the
+    // tower backward; after the first expert layer's act/BN backward) and waits for one (the row-wise backward):
+    //   main  : [dz] -> tower backward -> R(ev_b1) -> experts L(n-1)..L1 -> L0 act/BN backward -> R(fork) -> L0 dgrad -> W(ev_rw)
+    //   side  : [forward's deferred tail] -> grads init -> dcn GEMM -> gate-input GEMMs -> R'(ev_gates) -> weight gradients A (one
+    //           launch) | after the fork: weight gradients B (one launch) -> reductions -> waits for side2's last kernel
+    //   side2 : table L2 sweep (behind the side stream's position at entry) | W'(ev_gates) -> row-wise backward -> R'(ev_rw) ->
+    //           its parameter-gradient finish, group-embedding and gate-bias reductions
     // Issue order = the order in which a captured graph schedules independent branches (and the order a just-in-time host
-    // feeds the queues): the main stream's dependent chain is issued FIRST in every section, the side work behind it waits on
-    // events recorded at the right points of the main stream (mark_main / hipStreamWaitEvent).
+    // feeds the queues): the main stream's dependent chain is issued FIRST in every section.
     auto mark_main = [&](hipEvent_t* ev) -> int {
         *ev = x.m->ev[x.ev_next++ % (x.m->n_ev - 1)];
         AR_HIP(hipEventRecord(*ev, x.st));
@@ -790,25 +890,25 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     HeadsP hp = {};
     hp.prob = ws + x.w.prob; hp.dz = ws + x.w.dz; hp.n_heads = m->n_heads; hp.ld_h = m->ld_h; hp.B = c->B;
     hp.y = c->y; hp.seg_weight = c->seg_weight; hp.dprobs = dprobs; hp.level = LL; hp.r = x.r; hp.mp = x.mp;
-    if (dprobs || !c->y) LAUNCH(k_heads_dz, dim3(x.n_tiles * SUB), dim3(256), hp);   // else: fused into k_heads_fwd
-    hipEvent_t ev_b0;                                        // dz and the forward's results are final
-    TRY(mark_main(&ev_b0));
+    if (dprobs || !c->y) LAUNCH(k_heads_dz, dim3(x.n_tiles * SUB), dim3(256), hp);   // else: fused into k_heads_fwd / k_tower_fwd
+    const bool tail_deferred = m->fwd_tail_deferred;         // fused step: the forward left its loss / running-statistics tail to us
+    m->fwd_tail_deferred = false;
     const bool fused_bwd = c->train && tower_fused_bwd_ok(x);
     const int nle = m->experts.n_layers;
     AR_CHECK_ARG(m->n_heads * m->h_last <= 1024, "aread_backward: n_heads*h_last too large");
-    auto table_l2_pass = [&]() -> int {
-        // the caller's embedding-table L2 sweep, released now: it runs beside the tower backward (a chain of latency-bound
-        // phases that leaves the HBM idle) on the second side stream, which joins the main stream at the end of the call
-        if (!c->l2_table) return AREAD_OK;
-        AR_HIP(hipStreamWaitEvent(m->side2, ev_b0, 0));
+    // the caller's embedding-table L2 sweep, released now on the second side stream behind the side stream's position at
+    // entry (the forward's side prologue): it runs beside the tower kernels (chains of latency-bound phases that leave the
+    // HBM idle) and is complete on `stream` when this call returns (W(ev_rw) below covers it)
+    if (c->l2_table) {
+        hipEvent_t ev_s0 = x.m->ev[x.ev_next++ % (x.m->n_ev - 1)];
+        AR_HIP(hipEventRecord(ev_s0, x.side));
+        AR_HIP(hipStreamWaitEvent(m->side2, ev_s0, 0));
         TRY(aread_l2_table_throttled(c->l2_table, c->l2_n, c->l2_coef, 1.0f, c->l2_grad, c->l2_partial, c->l2_workgroups, m->side2));
         TRY(aread_l2_finish(c->l2_partial, aread_l2_partials(), c->l2_coef, c->l2_reg_out, 0, m->side2));
-        return AREAD_OK;
-    };
+    }
     // dV[:, :D] = dz^T cn: queued for the side stream
     TRY(wgrad(x, ws + x.w.dz, m->ld_h, 0, ws + x.w.cn, D, 0, 1, m->n_heads, D, grads + m->head_w, m->head_ld, 0, nullptr, x.w.slab_head));
     phase_mark(x.st, 4);
-    TRY(table_l2_pass());
     if (fused_bwd) {
         // 2.-4. heads backward, tower pyramid, gate-mix and MMoE-mix backward: one launch
         TRY(tower_fused_bwd(x, grads));
@@ -819,7 +919,6 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     hb.dz = ws + x.w.dz; hb.act = ws + last.Act; hb.head_w = P + m->head_w; hb.head_ld = m->head_ld; hb.D = D; hb.h = m->h_last;
     hb.n_heads = m->n_heads; hb.ld_h = m->ld_h; hb.dact = ws + last.dAct; hb.dlin = ws + x.w.dlin;
     hb.part = ws + x.w.misc_part; hb.ldp = 1024; hb.r = x.r;
-    AR_CHECK_ARG(m->n_heads * m->h_last <= 1024, "aread_backward: n_heads*h_last too large");
     LAUNCH(k_heads_bwd, dim3(x.n_tiles * SUB), dim3(256), hb);
     // 3. tower pyramid, top down (the weight gradients queue up)
     for (int l = LL; l >= 0; --l) {
@@ -863,17 +962,14 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     // 5a. experts, all layers but the first: main stream, issued before any side work
     for (int j = nle - 1; j >= 1; --j)
         TRY(layer_bwd(x, m->experts.L[j], x.w.ex[j], ws + x.w.ex[j - 1].Act, ws + x.w.ex[j - 1].dAct, 0, grads, -1, x.w.slab_ex[j]));
-    hipEvent_t ev_b2;                                        // dH of those layers is final
-    TRY(mark_main(&ev_b2));
-    // ---- side stream: gradient buffer initialisation + dcn (need only dz), then batch A behind the tower backward, then the
-    // deeper expert layers' weight gradients and the reductions of everything so far (batch B) ----------------------------
+    // ---- side stream, batch A ------------------------------------------------------------------------------------------------
     x.st = x.side;
-    AR_HIP(hipStreamWaitEvent(x.side, ev_b0, 0));
-    AR_HIP(hipMemsetAsync(grads, 0, (size_t)m->n_params * sizeof(float), x.st));
+    AR_HIP(hipStreamWaitEvent(x.side, ev_b1, 0));      // (the side stream's first wait of this call: dz, dglog*, dH of the towers are final)
+    if (tail_deferred) TRY(forward_tail(x, tower_fused_ok(x)));
+    if (!c->grads_init) AR_HIP(hipMemsetAsync(grads, 0, (size_t)m->n_params * sizeof(float), x.st));   // every reduction below ADDS to grads
     // dcn = dz V[:, :D]
     TRY(simple_gemm(x, ws + x.w.dz, m->ld_h, true, P + m->head_w, m->head_ld, false, ws + x.w.dcn, D, nullptr, (int)x.rows, D,
                     m->n_heads, 0, 1));
-    AR_HIP(hipStreamWaitEvent(x.side, ev_b1, 0));
     if (m->gate_rows == 0) AR_HIP(hipMemsetAsync(ws + x.w.dq, 0, (size_t)x.rows * 2 * E * sizeof(float), x.st));
     // gate-input gradients first: dq = dglogT Tw (tower gates) and deg = dglogE Gw (MMoE gates) feed the row-wise backward
     if (m->gate_rows > 0)
@@ -883,24 +979,25 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
                     n_ge, 0, 1));
     hipEvent_t ev_gates = x.m->ev[x.ev_next++ % (x.m->n_ev - 1)];
     AR_HIP(hipEventRecord(ev_gates, x.side));
+    TRY(flush_wgrads_range(x, 0, n_pend_a));             // head, tower and gate weight gradients: one launch
     x.st = main_st;
-    hipEvent_t ev_rw = x.m->ev[x.ev_next++ % (x.m->n_ev - 1)];
-    static int rw_early = -1, dgrad_wait_only = -1;
-    if (rw_early < 0) { const char* e = getenv("AREAD_RW_EARLY"); rw_early = e ? atoi(e) : 0; }
-    if (dgrad_wait_only < 0) { const char* e = getenv("AREAD_DGRAD_WAIT_ONLY"); dgrad_wait_only = e ? atoi(e) : 1; }
-    const hipStream_t rw_stream = m->side2;
-    auto issue_rowwise = [&]() -> int {
-    // 4a. row-wise trunk backward on the second side stream, beside the expert backward: it needs dcn / dlin and dq / deg
-    // (all ordered behind ev_gates on the side stream) and WRITES de_out; the expert-L1 dgrad accumulates onto it later.
+    // ---- side2: row-wise trunk backward beside the expert backward.  It needs dcn / dlin and dq / deg (all ordered behind
+    // ev_gates on the side stream) and WRITES its share of dL/de: into c->de_rw when the caller gave one (the embedding
+    // backward then reads de_out + de_rw and the first expert layer's dgrad does not depend on this chain at all), else into
+    // de_out, onto which that dgrad accumulates behind ev_rw.
     // (No stream ever waits on its own event and no two forked streams wait on each other: hipStreamEndCapture walks the
-    // fork relation recursively and does not terminate on such a cycle.)
+    // fork relation recursively and does not terminate on such a cycle -- side2 waits on side, side waits on side2 only at
+    // the very end, after side2's last wait on side.)
+    hipEvent_t ev_rw = x.m->ev[x.ev_next++ % (x.m->n_ev - 1)];
+    const hipStream_t rw_stream = m->side2;
+    float* de_rw = c->de_rw ? c->de_rw : de_out;
     {
         AR_HIP(hipStreamWaitEvent(rw_stream, ev_gates, 0));
         x.st = rw_stream;
         RowwiseBwdP rb = {};
         rb.e = e_in; rb.xw = ws + x.w.xw; rb.dcn = ws + x.w.dcn; rb.dlin = ws + x.w.dlin; rb.dq = ws + x.w.dq; rb.deg = ws + x.w.deg;
         rb.lin_w = P + m->lin_w; rb.cn_w = P + m->cn_w; rb.cn_b = P + m->cn_b;
-        rb.de = de_out; rb.part = ws + x.w.rw_part; rb.part_ld = (int64_t)(cfg.n_cross + 2) * D + 8; rb.dgrp_part = ws + x.w.dgrp_part;
+        rb.de = de_rw; rb.part = ws + x.w.rw_part; rb.part_ld = (int64_t)(cfg.n_cross + 2) * D + 8; rb.dgrp_part = ws + x.w.dgrp_part;
         rb.D = D; rb.E = E; rb.n_cross = cfg.n_cross; rb.dom_field = cfg.domain_field; rb.rows = x.rows; rb.de_init = 1; rb.r = x.r;
         AR_CHECK_ARG(D <= 1024 && cfg.n_cross <= MAX_CROSS, "aread_backward: D=%d > 1024 or too many cross layers", D);
         if (D <= 384) launch_rowwise_bwd<3>(x, rb); else if (D <= 768) launch_rowwise_bwd<6>(x, rb); else launch_rowwise_bwd<8>(x, rb);
@@ -919,58 +1016,47 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
         }
         LAUNCH(k_seg_reduce, dim3(c->n_seg, cdiv(E, 16)), dim3(256), ws + x.w.dgrp_part, (int64_t)E, E, ws + x.w.grp, RWB_SUB, x.r);
         LAUNCH(k_grp_bwd, dim3(1), dim3(256), ws + x.w.grp, grads + m->group_emb, cfg.n_tower[0], E, x.r, x.mp);
+        // head tails (partials of the heads backward) and the gate biases (column sums of the gate-logit gradients): two
+        // launches here, behind the row-wise chain (nothing waits for them before the end of the call), instead of five
+        // serial ones in front of the weight gradients on the side stream
+        {
+            ColsumAllP ca = {};
+            ca.d[ca.n++] = ColsumOne{ws + x.w.dglogE, (int64_t)m->ld_ge, n_ge, ws + x.w.cs_part_e, (int64_t)m->ld_ge};
+            if (m->gate_rows > 0) ca.d[ca.n++] = ColsumOne{ws + x.w.dglogT, (int64_t)m->ld_gt, m->gate_rows, ws + x.w.cs_part_t, (int64_t)m->ld_gt};
+            ca.r = x.r;
+            LAUNCH(k_colsum_all, dim3(x.n_tiles, ca.n), dim3(256), ca);
+            ReduceAllP ra = {};
+            ra.d[ra.n++] = ReduceOne{ws + x.w.misc_part, (int64_t)1024, m->n_heads * m->h_last, grads + m->head_w + D, m->h_last, (int64_t)m->head_ld, SUB};
+            ra.d[ra.n++] = ReduceOne{ws + x.w.cs_part_e, (int64_t)m->ld_ge, n_ge, grads + m->gate_b, n_ge, (int64_t)0, 1};
+            if (m->gate_rows > 0) ra.d[ra.n++] = ReduceOne{ws + x.w.cs_part_t, (int64_t)m->ld_gt, m->gate_rows, grads + m->tgate_b, m->gate_rows, (int64_t)0, 1};
+            ra.r = x.r;
+            int mxc = m->n_heads * m->h_last;
+            if (n_ge > mxc) mxc = n_ge;
+            if (m->gate_rows > mxc) mxc = m->gate_rows;
+            LAUNCH(k_reduce_tiles_all, dim3(cdiv(mxc, 32), ra.n), dim3(256), ra);
+        }
         x.st = main_st;
     }
-        return AREAD_OK;
-    };
-    auto issue_side_rest = [&]() -> int {
+    // 5b. the first expert layer: its input gradient goes to de_out; without a separate de_rw it ADDS onto what the row-wise
+    // backward (side2) has written there
+    TRY(layer_bwd(x, m->experts.L[0], x.w.ex[0], e_in, de_out, c->de_rw ? 0 : 1, grads, -1, x.w.slab_ex[0], c->de_rw ? nullptr : ev_rw,
+                  true));
+    phase_mark(x.st, 7);
+    if (c->de_rw) AR_HIP(hipStreamWaitEvent(x.st, ev_rw, 0));   // (long finished: de_rw and the table L2 sweep are complete on `stream`)
+    // ---- side stream, batch B (its fork was recorded inside layer_bwd, right behind the act/BN backward and BEFORE the dgrad):
+    // every expert layer's weight gradient in one launch, then the reductions of everything
     x.st = x.side;
-    // head tails (partials of the heads backward), gate biases: all through misc_part, in this order on this one stream
-    LAUNCH(k_reduce_tiles, dim3(cdiv(m->n_heads * m->h_last, 32)), dim3(256), ws + x.w.misc_part, (int64_t)1024, m->n_heads * m->h_last,
-           grads + m->head_w + D, m->h_last, (int64_t)m->head_ld, 0, SUB, x.r);
-    LAUNCH(k_colsum, dim3(x.n_tiles), dim3(256), ws + x.w.dglogE, (int64_t)m->ld_ge, n_ge, ws + x.w.misc_part, (int64_t)1024, x.r);
-    LAUNCH(k_reduce_tiles, dim3(cdiv(n_ge, 32)), dim3(256), ws + x.w.misc_part, (int64_t)1024, n_ge, grads + m->gate_b, n_ge,
-           (int64_t)0, 0, 1, x.r);
-    if (m->gate_rows > 0) {
-        LAUNCH(k_colsum, dim3(x.n_tiles), dim3(256), ws + x.w.dglogT, (int64_t)m->ld_gt, m->gate_rows, ws + x.w.misc_part,
-               (int64_t)1024, x.r);
-        LAUNCH(k_reduce_tiles, dim3(cdiv(m->gate_rows, 32)), dim3(256), ws + x.w.misc_part, (int64_t)1024, m->gate_rows,
-               grads + m->tgate_b, m->gate_rows, (int64_t)0, 0, 1, x.r);
-    }
-    TRY(flush_wgrads_range(x, 0, n_pend_a));             // head, tower and gate weight gradients
-    AR_HIP(hipStreamWaitEvent(x.side, ev_b2, 0));
-    TRY(flush_wgrads_range(x, n_pend_a, x.n_pend));      // expert layers n-1 .. 1
+    TRY(flush_wgrads_range(x, n_pend_a, x.n_pend));
     x.n_pend = 0;
     TRY(flush_reductions(x));
     x.st = main_st;
-        return AREAD_OK;
-    };
-    if (rw_early) { TRY(issue_rowwise()); TRY(issue_side_rest()); }
-    else { TRY(issue_side_rest()); TRY(issue_rowwise()); }
-    // 5b. the first expert layer ADDS its input gradient onto de_out, which the row-wise backward (side2) has initialised
-    if (!dgrad_wait_only) AR_HIP(hipStreamWaitEvent(x.st, ev_rw, 0));
-    TRY(layer_bwd(x, m->experts.L[0], x.w.ex[0], e_in, de_out, 1, grads, -1, x.w.slab_ex[0], dgrad_wait_only ? ev_rw : nullptr));
-    phase_mark(x.st, 7);
-    // ---- side batch C (one fork): the first expert layer's weight gradient and its reductions
-    TRY(flush_wgrads(x, true));
-    x.st = x.side;
-    TRY(flush_reductions(x));
-    x.st = main_st;
-    if (c->l2_table && c->l2_dense_coef) {
-        // (A/B only, measured slower) dense L2 terms behind the last reduction, on the SECOND side stream
-        hipEvent_t e3 = x.m->ev[x.ev_next++ % (x.m->n_ev - 1)];
-        AR_HIP(hipEventRecord(e3, x.side));
-        AR_HIP(hipStreamWaitEvent(m->side2, e3, 0));
-        TRY(aread_l2_dense(x.params, c->l2_dense_coef, m->n_params, grads, c->l2_reg_out, 1, m->side2));
-    }
-    {   // the second side stream (row-wise parameter gradients, table L2 sweep: finished long ago) joins the main stream
-        hipEvent_t e2 = x.m->ev[x.ev_next++ % (x.m->n_ev - 1)];
-        AR_HIP(hipEventRecord(e2, rw_stream));
-        AR_HIP(hipStreamWaitEvent(main_st, e2, 0));
-    }
-    // de_out is complete on the main stream here; the parameter gradients complete on the side stream.
+    // de_out (and de_rw) are complete on the main stream here; the parameter gradients complete on the two side streams
+    // (side: weight / bias / BatchNorm gradients; side2: row-wise trunk, group embedding, gate biases, head tails).
     // async_tail: the caller overlaps its own work (embedding scatter) and calls aread_join() afterwards.
-    if (!(c->async_tail & 1)) TRY(join_side(x));
+    // (side never waits on side2 -- side2 has waited on side, and hipStreamEndCapture does not terminate on such a cycle:
+    // tests/test_gpu_graph.py -- so the join makes the main stream wait for both.)
+    m->side2_pending = true;
+    if (!(c->async_tail & 1)) TRY(aread_join(m, stream));
     return AREAD_OK;
 }
 
@@ -1004,6 +1090,11 @@ extern "C" int aread_join(const aread_model* m, void* stream) {
     hipEvent_t e = m->ev[m->n_ev - 1];
     AR_HIP(hipEventRecord(e, m->side));
     AR_HIP(hipStreamWaitEvent((hipStream_t)stream, e, 0));
+    if (m->side2_pending) {
+        AR_HIP(hipEventRecord(m->ev_join2, m->side2));
+        AR_HIP(hipStreamWaitEvent((hipStream_t)stream, m->ev_join2, 0));
+        m->side2_pending = false;
+    }
     return AREAD_OK;
 }
 
@@ -1123,7 +1214,20 @@ extern "C" int aread_l2_dense_total(const float* params, const float* coef, int6
     AR_CHECK_ARG(params && coef && loss_out && n > 0, "aread_l2_dense: bad arguments");
     // the block partials live at the tail of loss_out's caller-provided scratch: loss_out[1..256]; the last block finishes
     hipLaunchKernelGGL(k_l2_dense, dim3(256), dim3(256), 0, (hipStream_t)stream, params, coef, n, grads, loss_out + 1, loss_out,
-                       accumulate, loss_in, total_out);
+                       accumulate, loss_in, total_out, 0);
+    AR_LAUNCH_CHECK();
+    return AREAD_OK;
+}
+extern "C" int aread_l2_dense_init(const float* params, const float* coef, int64_t n, float* grads, float* reg_out, void* stream) {
+    AR_CHECK_ARG(params && coef && grads && reg_out && n > 0, "aread_l2_dense_init: bad arguments");
+    hipLaunchKernelGGL(k_l2_dense, dim3(256), dim3(256), 0, (hipStream_t)stream, params, coef, n, grads, reg_out + 1, reg_out,
+                       0, (const float*)nullptr, (float*)nullptr, 1);
+    AR_LAUNCH_CHECK();
+    return AREAD_OK;
+}
+extern "C" int aread_step_total(const float* loss, const float* reg_dense, float* reg, float* total, void* stream) {
+    AR_CHECK_ARG(loss && reg_dense && reg && total, "aread_step_total: null pointer");
+    hipLaunchKernelGGL(k_step_total, dim3(1), dim3(64), 0, (hipStream_t)stream, loss, reg_dense, reg, total);
     AR_LAUNCH_CHECK();
     return AREAD_OK;
 }

@@ -107,6 +107,59 @@ __global__ __launch_bounds__(256) void k_colsum(const float* X, int64_t ldx, int
     }
 }
 
+// k_colsum for up to 4 inputs in one launch (grid (n_tiles, n)): the bias gradients of the gate layers
+struct ColsumOne { const float* X; int64_t ldx; int ncols; float* part; int64_t ldp; };
+struct ColsumAllP { int n; ColsumOne d[4]; RowsP r; };
+__global__ __launch_bounds__(256) void k_colsum_all(const ColsumAllP a) {
+    __shared__ float s_acc[16][17];
+    const ColsumOne& p = a.d[blockIdx.y];
+    const int tile = blockIdx.x;
+    if (a.r.tile_seg[tile] < 0) return;
+    const int nvalid = a.r.tile_valid[tile];
+    const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    for (int cb = 0; cb < p.ncols; cb += 16) {
+        const int c = cb + cl;
+        float s = 0.f;
+        if (c < p.ncols)
+            for (int rr = rg; rr < nvalid; rr += 16) s += p.X[((int64_t)tile * TILE_M + rr) * p.ldx + c];
+        s_acc[rg][cl] = s;
+        __syncthreads();
+        if (rg == 0 && c < p.ncols) {
+            float tot = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) tot += s_acc[k][cl];
+            p.part[(int64_t)tile * p.ldp + c] = tot;
+        }
+        __syncthreads();
+    }
+}
+
+// k_reduce_tiles for up to 4 partial buffers in one launch (grid (max column blocks, n)); the sums are ADDED to out
+struct ReduceOne { const float* part; int64_t ld; int ncols; float* out; int gw; int64_t gs; int sub; };
+struct ReduceAllP { int n; ReduceOne d[4]; RowsP r; };
+__global__ __launch_bounds__(256) void k_reduce_tiles_all(const ReduceAllP a) {
+    __shared__ float s_acc[8][33];
+    const ReduceOne& p = a.d[blockIdx.y];
+    if ((int)blockIdx.x * 32 >= p.ncols) return;
+    const int cl = threadIdx.x & 31, tg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    float s = 0.f;
+    if (c < p.ncols) {
+        const int n_slots = a.r.hdr[PLAN_NTILES] * p.sub;
+#pragma unroll 8
+        for (int t = tg; t < n_slots; t += 8) s += p.part[(int64_t)t * p.ld + c];
+    }
+    s_acc[tg][cl] = s;
+    __syncthreads();
+    if (tg == 0 && c < p.ncols) {
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tot += s_acc[k][cl];
+        float* o = p.out + (int64_t)(c / p.gw) * p.gs + (c % p.gw);
+        *o += tot;
+    }
+}
+
 // batched weight transposes: WT[g][i][o] = W[g][o][i]   (grid.y = layer; weights are small)
 struct TransOne { const float* W; float* WT; int G, out, in; };
 struct TransAllP { int n; TransOne d[MAX_BN_LAYERS_DECL]; };
@@ -165,16 +218,19 @@ __global__ __launch_bounds__(256) void k_splitk_reduce_all(const SplitKAllP a) {
             const int g = (int)(idx / ((int64_t)p.M * p.N));
             const int rem = (int)(idx - (int64_t)g * p.M * p.N);
             const int m = rem / p.N, n = rem - m * p.N;
+            // the gradient buffer holds its initial value (zero, or the dense L2 term 2*coef*w): the sums are ADDED to it
             if (!vec) {
-                if (p.transposed) p.out[(int64_t)g * p.o_gs + (int64_t)n * p.ldo + m] = t.x;
-                else p.out[(int64_t)g * p.o_gs + (int64_t)m * p.ldo + n] = t.x;
+                if (p.transposed) p.out[(int64_t)g * p.o_gs + (int64_t)n * p.ldo + m] += t.x;
+                else p.out[(int64_t)g * p.o_gs + (int64_t)m * p.ldo + n] += t.x;
             } else if (p.transposed) {                         // the slab holds the transposed product
                 float* o = p.out + (int64_t)g * p.o_gs + (int64_t)n * p.ldo + m;
-                o[0] = t.x; o[p.ldo] = t.y; o[2 * p.ldo] = t.z; o[3 * p.ldo] = t.w;
+                o[0] += t.x; o[p.ldo] += t.y; o[2 * p.ldo] += t.z; o[3 * p.ldo] += t.w;
             } else {
                 float* o = p.out + (int64_t)g * p.o_gs + (int64_t)m * p.ldo + n;
-                if ((p.ldo & 3) == 0 && (p.o_gs & 3) == 0 && (((uintptr_t)p.out) & 15) == 0) *(float4*)o = t;
-                else { o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w; }
+                if ((p.ldo & 3) == 0 && (p.o_gs & 3) == 0 && (((uintptr_t)p.out) & 15) == 0) {
+                    const float4 b = *(const float4*)o;
+                    *(float4*)o = make_float4(b.x + t.x, b.y + t.y, b.z + t.z, b.w + t.w);
+                } else { o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w; }
             }
         }
         __syncthreads();
@@ -222,7 +278,7 @@ __global__ __launch_bounds__(256) void k_bias_reduce_all(const BiasAllP a) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) tot += s_acc[tg][k][cl];
         float* o = tg == 0 ? p.db : (tg == 1 ? p.dbeta : p.dgamma);
-        o[c] = tot;
+        o[c] += tot;
     }
 }
 
@@ -966,15 +1022,15 @@ __global__ __launch_bounds__(256) void k_rowwise_finish(const RowwiseFinP p) {
         float Bi = 0.f;                                   // B_i = sum_{j<i} b_j
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
-            p.g_cn_w[(int64_t)i * p.D + c] = tot[i] + Bi * S[i];
+            p.g_cn_w[(int64_t)i * p.D + c] += tot[i] + Bi * S[i];
             Bi += p.cn_b[(int64_t)i * p.D + c];
             float db = tot[NC + 1];
 #pragma unroll
             for (int j = i + 1; j < NC; ++j) db += p.cn_w[(int64_t)j * p.D + c] * S[j];
-            p.g_cn_b[(int64_t)i * p.D + c] = db;
+            p.g_cn_b[(int64_t)i * p.D + c] += db;
         }
-        p.g_lin_w[c] = tot[NC];
-        if (c == 0) p.g_lin_b[0] = S[NC];
+        p.g_lin_w[c] += tot[NC];
+        if (c == 0) p.g_lin_b[0] += S[NC];
     }
 }
 
@@ -990,7 +1046,7 @@ __global__ __launch_bounds__(256) void k_grp_bwd(const float* dgrp_seg, float* d
                 const int n0 = mp.n0act[seg];
                 acc += n0 > 1 ? s / (float)n0 : s;
             }
-        dgroup[i] = acc;
+        dgroup[i] += acc;
     }
 }
 
@@ -1029,25 +1085,38 @@ __global__ __launch_bounds__(256) void k_bn_running(const BnRunAllP a) {
 // ticket counter) adds the 256 partials in index order into loss_out[0] and, when asked, forms total = loss_in + loss_out[0]
 // (the step's final scalar) -- what used to be k_l2_dense + k_l2_finish + a torch.add at the serial tail of the step.
 __device__ unsigned g_l2_dense_ticket = 0;
+// 2*coef*w as one rounded product: the empty asm keeps hipcc from contracting it into an fma with whatever it is added to
+// (HIP's __fmul_rn is a plain multiply and would be contracted)
+__device__ __forceinline__ float l2_term(float c, float v) {
+    float t = 2.0f * c * v;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+// init != 0: grads is WRITTEN (= 2*coef*w, zero where coef is zero) instead of added to -- the step's gradient buffer starts
+// from the dense L2 term and every reduction of the backward adds onto it (same sums, commuted: bitwise the same result),
+// so the pass runs at the head of the step beside the forward instead of at its serial tail.
 __global__ __launch_bounds__(256) void k_l2_dense(const float* w, const float* coef, int64_t n, float* grads, float* partial,
-                                                  float* loss_out, int accumulate, const float* loss_in, float* total_out) {
+                                                  float* loss_out, int accumulate, const float* loss_in, float* total_out, int init) {
     float acc = 0.f;
     const int64_t n4 = ((((uintptr_t)w | (uintptr_t)coef | (uintptr_t)grads) & 15) == 0) ? n >> 2 : 0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         // all three loads in flight together (the gradient load used to wait for the coefficient test: two dependent round trips
         // per iteration on the serial tail of the step)
         const float4 c = ((const float4*)coef)[i], v = ((const float4*)w)[i];
-        float4 g = grads ? ((const float4*)grads)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 g = (grads && !init) ? ((const float4*)grads)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         acc += c.x * v.x * v.x; acc += c.y * v.y * v.y; acc += c.z * v.z * v.z; acc += c.w * v.w * v.w;
-        if (grads && (c.x != 0.f || c.y != 0.f || c.z != 0.f || c.w != 0.f)) {
-            g.x += 2.0f * c.x * v.x; g.y += 2.0f * c.y * v.y; g.z += 2.0f * c.z * v.z; g.w += 2.0f * c.w * v.w;
+        if (grads && (init || c.x != 0.f || c.y != 0.f || c.z != 0.f || c.w != 0.f)) {
+            // (l2_term: no contraction into an fma with the running gradient -- the term is the same rounded product whether
+            // it initialises the buffer or is added last, so both orders give bitwise the same gradient)
+            g.x += l2_term(c.x, v.x); g.y += l2_term(c.y, v.y); g.z += l2_term(c.z, v.z); g.w += l2_term(c.w, v.w);
             ((float4*)grads)[i] = g;
         }
     }
     for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float c = coef[i], v = w[i];
         acc += c * v * v;
-        if (grads && c != 0.f) grads[i] += 2.0f * c * v;
+        if (grads && init) grads[i] = l2_term(c, v);
+        else if (grads && c != 0.f) grads[i] += l2_term(c, v);
     }
     acc = wave_sum(acc);
     __shared__ float s[4];
@@ -1072,5 +1141,15 @@ __global__ __launch_bounds__(256) void k_l2_dense(const float* w, const float* c
         const float r = accumulate ? loss_out[0] + tot : tot;
         loss_out[0] = r;
         if (total_out) total_out[0] = (loss_in ? loss_in[0] : 0.f) + r;
+    }
+}
+
+// the step's final scalars once every contribution is known: reg[0] = reg_table (already in reg[0]) + reg_dense[0],
+// total = loss + reg[0]   (one thread; the sums are formed in the order the tail kernel k_l2_dense used to form them)
+__global__ void k_step_total(const float* loss, const float* reg_dense, float* reg, float* total) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const float r = reg[0] + reg_dense[0];
+        reg[0] = r;
+        total[0] = loss[0] + r;
     }
 }

@@ -294,7 +294,7 @@ static inline int rs_passes(int64_t n_rows) {
 
 template <bool GATHER, bool FINAL, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_segreduce(const int32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                       const v4f* __restrict__ src, int64_t n, int e4, float inv_div,
+                                                       const v4f* __restrict__ src, const v4f* __restrict__ src2, int64_t n, int e4, float inv_div,
                                                        v4f* __restrict__ grad, int32_t* __restrict__ bnd_keys,
                                                        v4f* __restrict__ bnd_vals) {
     extern __shared__ v4f smem[];
@@ -333,6 +333,7 @@ __global__ __launch_bounds__(THREADS) void k_segreduce(const int32_t* __restrict
 #pragma unroll
             for (int j = 0; j < SR_PW; ++j) {
                 g[j] = k[j] != SR_SENT ? src[(int64_t)(v[j] & 0x7FFFFFFFu) * e4 + c4] : zero;
+                if (src2 && k[j] != SR_SENT) g[j] += src2[(int64_t)(v[j] & 0x7FFFFFFFu) * e4 + c4];   // second addend of dL/de (aread_call.de_rw)
                 if (v[j] >> 31) g[j] *= inv_div;
             }
         } else {
@@ -483,7 +484,12 @@ extern "C" int aread_embed_bwd_sort(const int32_t* x, int64_t B, int f_in, const
 // phase 2: segmented reduction of the sorted pairs into table_grad
 extern "C" int aread_embed_bwd_reduce(int64_t B, int f_in, int E, int seq_len, const float* dout, float* table_grad, void* ws,
                                       void* stream) {
+    return aread_embed_bwd_reduce2(B, f_in, E, seq_len, dout, nullptr, table_grad, ws, stream);
+}
+extern "C" int aread_embed_bwd_reduce2(int64_t B, int f_in, int E, int seq_len, const float* dout, const float* dout2, float* table_grad,
+                                       void* ws, void* stream) {
     AR_CHECK_ARG(dout && table_grad && ws, "aread_embed_bwd_reduce: null pointer");
+    AR_CHECK_ARG(((uintptr_t)dout2 & 15) == 0, "aread_embed_bwd_reduce: alignment");
     AR_CHECK_ARG(E > 0 && E % 4 == 0 && E <= 256 && seq_len >= 1, "aread_embed_bwd_reduce: bad E/seq_len");
     AR_CHECK_ARG(((uintptr_t)dout & 15) == 0 && ((uintptr_t)table_grad & 15) == 0 && ((uintptr_t)ws & 255) == 0,
                  "aread_embed_bwd_reduce: alignment");
@@ -505,12 +511,12 @@ extern "C" int aread_embed_bwd_reduce(int64_t B, int f_in, int E, int seq_len, c
     const float inv = 1.0f / (float)seq_len;
     if (L.n <= cap_final) {
         hipLaunchKernelGGL((k_segreduce<true, true, SRF_THREADS>), dim3(1), dim3(SRF_THREADS), ldsf, st, keys_b, vals_b,
-                           (const v4f*)dout, L.n, e4, inv, (v4f*)table_grad, (int32_t*)nullptr, (v4f*)nullptr);
+                           (const v4f*)dout, (const v4f*)dout2, L.n, e4, inv, (v4f*)table_grad, (int32_t*)nullptr, (v4f*)nullptr);
         AR_LAUNCH_CHECK();
         return AREAD_OK;
     }
     hipLaunchKernelGGL((k_segreduce<true, false, SR_THREADS>), dim3((unsigned)L.n_blk), dim3(SR_THREADS), lds1, st, keys_b,
-                       vals_b, (const v4f*)dout, L.n, e4, inv, (v4f*)table_grad, bkeys, bvals);
+                       vals_b, (const v4f*)dout, (const v4f*)dout2, L.n, e4, inv, (v4f*)table_grad, bkeys, bvals);
     AR_LAUNCH_CHECK();
     int64_t n_cur = 2 * L.n_blk;
     const int32_t* ck = bkeys; const v4f* cv = bvals;
@@ -518,14 +524,14 @@ extern "C" int aread_embed_bwd_reduce(int64_t B, int f_in, int E, int seq_len, c
     while (n_cur > cap_final) {                                      // (B > ~30 k lookups-per-final-capacity: one more level)
         const int64_t per_block = (int64_t)nw1 * SR_PW, blocks = (n_cur + per_block - 1) / per_block;
         hipLaunchKernelGGL((k_segreduce<false, false, SR_THREADS>), dim3((unsigned)blocks), dim3(SR_THREADS), lds1, st, ck,
-                           (const uint32_t*)nullptr, cv, n_cur, e4, 1.f, (v4f*)table_grad, nk, nv);
+                           (const uint32_t*)nullptr, cv, (const v4f*)nullptr, n_cur, e4, 1.f, (v4f*)table_grad, nk, nv);
         AR_LAUNCH_CHECK();
         n_cur = 2 * blocks;
         const int32_t* tk = ck; const v4f* tv = cv;
         ck = nk; cv = nv; nk = (int32_t*)tk; nv = (v4f*)tv;
     }
     hipLaunchKernelGGL((k_segreduce<false, true, SRF_THREADS>), dim3(1), dim3(SRF_THREADS), ldsf, st, ck, (const uint32_t*)nullptr,
-                       cv, n_cur, e4, 1.f, (v4f*)table_grad, (int32_t*)nullptr, (v4f*)nullptr);
+                       cv, (const v4f*)nullptr, n_cur, e4, 1.f, (v4f*)table_grad, (int32_t*)nullptr, (v4f*)nullptr);
     AR_LAUNCH_CHECK();
     return AREAD_OK;
 }

@@ -557,32 +557,19 @@ __device__ __forceinline__ bf16x8 rc_fragment(const __bf16* img, int m0, int lan
     return u.v;
 }
 
+// one 64 x (16*NI) output tile of one (group, k-slice): shared by k_gemm_bf3_rc (one GEMM per launch) and k_gemm_bf3_rc_multi
+// (many small weight-gradient GEMMs in one launch).  s_lds: RC_LDS_BYTES(NI) bytes, 256-byte aligned; s_redf: 4 x 16*NI floats.
+#define RC_LDS_BYTES(NI) ((2 * (RcImage<64>::ELEMS + RcImage<16 * (NI)>::ELEMS) * 2) > (4 * 16 * (16 * (NI) + 4) * 4) ? \
+                          (2 * (RcImage<64>::ELEMS + RcImage<16 * (NI)>::ELEMS) * 2) : (4 * 16 * (16 * (NI) + 4) * 4))
 template <int NI>
-__global__ __launch_bounds__(GEMM_THREADS) void k_gemm_bf3_rc(const GemmP p) {
+__device__ __forceinline__ void gemm_bf3_rc_tile(const GemmP& p, int bx, int by, int bz, char* s_lds, float* s_redf) {
     constexpr int TM = 64, TN = 16 * NI;
-    constexpr int STAGE_B = 4 * 16 * (TN + 4) * 4;       // epilogue staging (bytes), overlays the operand tiles
-    constexpr int OPER_B = 2 * (RcImage<TM>::ELEMS + RcImage<TN>::ELEMS) * 2;
-    __shared__ __attribute__((aligned(256))) char s_lds[OPER_B > STAGE_B ? OPER_B : STAGE_B];
     __bf16* Ah = (__bf16*)s_lds;
     __bf16* Al = Ah + RcImage<TM>::ELEMS;
     __bf16* Bh = Al + RcImage<TM>::ELEMS;
     __bf16* Bl = Bh + RcImage<TN>::ELEMS;
-    __shared__ float s_red[4][TN];
-
+    float (*s_red)[TN] = (float (*)[TN])s_redf;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // XCD-aware mapping: all (m, n) tiles of one (group, k-slice) read the same k-rows of both operands, so they are given
-    // to ONE XCD (workgroups are dealt round-robin over the 8 XCDs in dispatch order): the slice is then fetched into one L2
-    // instead of eight (PMC: 228 MB of HBM traffic per expert-L1 launch without it, 3.3x the compulsory traffic).
-    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if ((gridDim.z & 7) == 0) {
-        const int bps = gridDim.x * gridDim.y;
-        const int id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        const int xcd = id & 7, slot = id >> 3;
-        bz = (slot / bps) * 8 + xcd;
-        const int mn = slot - (slot / bps) * bps;
-        by = mn / gridDim.x;
-        bx = mn - by * gridDim.x;
-    }
     const int g = bz / p.k_split, ks = bz - g * p.k_split;
     const int m0 = by * TM, n0 = bx * TN;
     const float* Ag = p.A + (int64_t)g * p.a_gs;
@@ -639,6 +626,82 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm_bf3_rc(const GemmP p) {
     gemm_epilogue<NI>(p, acc, g, ks, m0, n0, by, s_red, (float*)s_lds);
 }
 
+// XCD-aware mapping: all (m, n) tiles of one (group, k-slice) read the same k-rows of both operands, so they are given
+// to ONE XCD (workgroups are dealt round-robin over the 8 XCDs in dispatch order): the slice is then fetched into one L2
+// instead of eight (PMC: 228 MB of HBM traffic per expert-L1 launch without it, 3.3x the compulsory traffic).
+// id: block index inside this GEMM's (nx, ny, nz) grid, dealt in dispatch order (id & 7 == the dispatching XCD's slot).
+__device__ __forceinline__ void rc_block_map(int id, int nx, int ny, int nz, int* bx, int* by, int* bz) {
+    const int bps = nx * ny;
+    if ((nz & 7) == 0) {
+        const int xcd = id & 7, slot = id >> 3;
+        *bz = (slot / bps) * 8 + xcd;
+        const int mn = slot - (slot / bps) * bps;
+        *by = mn / nx;
+        *bx = mn - *by * nx;
+    } else {
+        *bz = id / bps;
+        const int mn = id - *bz * bps;
+        *by = mn / nx;
+        *bx = mn - *by * nx;
+    }
+}
+
+template <int NI>
+__global__ __launch_bounds__(GEMM_THREADS) void k_gemm_bf3_rc(const GemmP p) {
+    __shared__ __attribute__((aligned(256))) char s_lds[RC_LDS_BYTES(NI)];
+    __shared__ float s_red[4 * 16 * NI];
+    int bx, by, bz;
+    rc_block_map(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x, gridDim.y, gridDim.z, &bx, &by, &bz);
+    gemm_bf3_rc_tile<NI>(p, bx, by, bz, s_lds, s_red);
+}
+
+// ---- many small weight-gradient GEMMs in ONE launch ------------------------------------------------------------------------
+// The backward queues ~13 of them (heads, six tower layers, two gate layers, the deeper expert layers): as separate launches
+// they are a serial chain of 8-22 us kernels with a dozen workgroups each on the side stream (~190 us, the step's tail waited
+// for it); in one launch they run side by side.  Each GEMM keeps its own tile width (NI) and split-K geometry; its blocks
+// start at a multiple of 8 so that the XCD mapping above holds per GEMM.
+#define RC_MULTI_MAX 20
+struct RcDesc {
+    const float* A; int64_t lda, a_gs;
+    const float* B; int64_t ldb, b_gs;
+    float* C; int64_t c_gs, c_ks;
+    const uint8_t* active;
+    int M, N, K, G, k_split, k_chunk;
+    int ni, nx, ny, nz;
+};
+struct RcMultiP {
+    int n;
+    int first[RC_MULTI_MAX + 1];                      // first[i]: first block of GEMM i (multiple of 8); first[n]: grid size
+    RcDesc d[RC_MULTI_MAX];
+    const int32_t* tile_seg; int active_ld, gate_axis;
+};
+#ifdef GEMM_RC_MULTI_IMPL          // defined by gemm.hip only: a non-template kernel must live in one translation unit
+__global__ __launch_bounds__(GEMM_THREADS) void k_gemm_bf3_rc_multi(const RcMultiP a) {
+    __shared__ __attribute__((aligned(256))) char s_lds[RC_LDS_BYTES(8)];
+    __shared__ float s_red[4 * 16 * 8];
+    int i = 0;
+    while (i + 1 < a.n && (int)blockIdx.x >= a.first[i + 1]) ++i;        // (block-uniform)
+    const RcDesc& d = a.d[i];
+    const int id = blockIdx.x - a.first[i];
+    if (id >= d.nx * d.ny * d.nz) return;                                // padding up to the next multiple of 8
+    GemmP p = {};
+    p.A = d.A; p.lda = d.lda; p.a_gs = d.a_gs;
+    p.B = d.B; p.ldb = d.ldb; p.b_gs = d.b_gs;
+    p.C = d.C; p.ldc = d.N; p.c_gs = d.c_gs; p.c_ks = d.c_ks;
+    p.M = d.M; p.N = d.N; p.K = d.K; p.G = d.G; p.k_split = d.k_split; p.k_chunk = d.k_chunk;
+    p.tile_seg = a.tile_seg; p.active = d.active; p.active_ld = a.active_ld; p.gate_axis = a.gate_axis;
+    int bx, by, bz;
+    rc_block_map(id, d.nx, d.ny, d.nz, &bx, &by, &bz);
+    switch (d.ni) {
+        case 8: gemm_bf3_rc_tile<8>(p, bx, by, bz, s_lds, s_red); break;
+        case 6: gemm_bf3_rc_tile<6>(p, bx, by, bz, s_lds, s_red); break;
+        case 4: gemm_bf3_rc_tile<4>(p, bx, by, bz, s_lds, s_red); break;
+        case 2: gemm_bf3_rc_tile<2>(p, bx, by, bz, s_lds, s_red); break;
+        default: gemm_bf3_rc_tile<1>(p, bx, by, bz, s_lds, s_red); break;
+    }
+}
+#endif
+
 // number of 16-column MFMA tiles per wave: 96-wide tiles when they cover N with less padding than 128-wide ones
 static inline int gemm_ni(int N) {
     if (N > 64) {
@@ -652,3 +715,5 @@ int launch_gemm(const GemmP& p, bool a_kc, bool b_kc, hipStream_t st);
 int launch_gemm_bf3(const GemmP& p, hipStream_t st);
 // split-bf16 variant for two row-contiguous operands (weight gradients); split-K and k-tile gating as launch_gemm
 int launch_gemm_bf3_rc(const GemmP& p, hipStream_t st);
+// n such GEMMs (split-K slabs with ldc = N, the same tile_seg / gate_axis) in one launch
+int launch_gemm_bf3_rc_multi(const GemmP* p, int n, hipStream_t st);

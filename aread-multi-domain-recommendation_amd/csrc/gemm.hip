@@ -1,5 +1,6 @@
 // gemm.hip -- instantiations + launcher of the grouped fp32-MFMA GEMM (see gemm.h).
 #include <cstdlib>
+#define GEMM_RC_MULTI_IMPL
 #include "gemm_wide.h"
 
 template <int NI>
@@ -75,6 +76,42 @@ int launch_gemm_bf3_rc(const GemmP& p_in, hipStream_t st) {
         default: hipLaunchKernelGGL((k_gemm_bf3_rc<1>), grid, dim3(GEMM_THREADS), 0, st, p); break;
     }
     AR_LAUNCH_CHECK();
+    return AREAD_OK;
+}
+
+int launch_gemm_bf3_rc_multi(const GemmP* ps, int n, hipStream_t st) {
+    if (n <= 0) return AREAD_OK;
+    if (n == 1) return launch_gemm_bf3_rc(ps[0], st);
+    for (int lo = 0; lo < n; lo += RC_MULTI_MAX) {
+        const int cnt = n - lo < RC_MULTI_MAX ? n - lo : RC_MULTI_MAX;
+        RcMultiP a = {};
+        a.n = cnt;
+        int blocks = 0;
+        for (int i = 0; i < cnt; ++i) {
+            GemmP p = ps[lo + i];
+            AR_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0 && p.G > 0, "gemm_bf3_rc_multi: empty problem");
+            AR_CHECK_ARG(p.lda % 4 == 0 && p.ldb % 4 == 0 && p.a_gs % 4 == 0 && p.b_gs % 4 == 0, "gemm_bf3_rc_multi: strides must be multiples of 4");
+            AR_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.B & 15) == 0, "gemm_bf3_rc_multi: operands must be 16-byte aligned");
+            if (p.k_split < 1) p.k_split = 1;
+            if (p.k_split == 1) p.k_chunk = p.K;
+            AR_CHECK_ARG(p.k_split == 1 || p.k_chunk % TILE_M == 0, "gemm_bf3_rc_multi: k_chunk must be a multiple of %d", TILE_M);
+            AR_CHECK_ARG(p.ldc == p.N && !p.accumulate && !p.bias && !p.stat_part, "gemm_bf3_rc_multi: plain split-K slabs only");
+            AR_CHECK_ARG(p.gate_axis == ps[lo].gate_axis && p.tile_seg == ps[lo].tile_seg && p.active_ld == ps[lo].active_ld,
+                         "gemm_bf3_rc_multi: the GEMMs of one launch share the row plan");
+            AR_CHECK_ARG(p.gate_axis == 0 || (p.gate_axis == 2 && p.tile_seg != nullptr), "gemm_bf3_rc_multi: only k-tile gating is supported");
+            RcDesc& d = a.d[i];
+            d.A = p.A; d.lda = p.lda; d.a_gs = p.a_gs; d.B = p.B; d.ldb = p.ldb; d.b_gs = p.b_gs;
+            d.C = p.C; d.c_gs = p.c_gs; d.c_ks = p.c_ks; d.active = p.active;
+            d.M = p.M; d.N = p.N; d.K = p.K; d.G = p.G; d.k_split = p.k_split; d.k_chunk = p.k_chunk;
+            d.ni = gemm_ni(p.N); d.nx = cdiv(p.N, 16 * d.ni); d.ny = cdiv(p.M, 64); d.nz = p.G * p.k_split;
+            a.first[i] = blocks;
+            blocks += (d.nx * d.ny * d.nz + 7) / 8 * 8;
+        }
+        a.first[cnt] = blocks;
+        a.tile_seg = ps[lo].tile_seg; a.active_ld = ps[lo].active_ld; a.gate_axis = ps[lo].gate_axis;
+        hipLaunchKernelGGL(k_gemm_bf3_rc_multi, dim3(blocks), dim3(GEMM_THREADS), 0, st, a);
+        AR_LAUNCH_CHECK();
+    }
     return AREAD_OK;
 }
 

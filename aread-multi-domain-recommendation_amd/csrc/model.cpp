@@ -156,6 +156,7 @@ int model_streams_init(const aread_model* m) {
     AR_HIP(hipStreamCreateWithFlags(&m->side2, hipStreamNonBlocking));
     for (int i = 0; i < 64; ++i) AR_HIP(hipEventCreateWithFlags(&m->ev[i], hipEventDisableTiming));
     AR_HIP(hipEventCreateWithFlags(&m->ev_prep, hipEventDisableTiming));
+    AR_HIP(hipEventCreateWithFlags(&m->ev_join2, hipEventDisableTiming));
     m->n_ev = 64;
     return AREAD_OK;
 }
@@ -165,6 +166,7 @@ extern "C" void aread_model_destroy(aread_model* m) {
     if (m->side) {
         for (int i = 0; i < m->n_ev; ++i) (void)hipEventDestroy(m->ev[i]);
         if (m->ev_prep) (void)hipEventDestroy(m->ev_prep);
+        if (m->ev_join2) (void)hipEventDestroy(m->ev_join2);
         (void)hipStreamDestroy(m->side);
         if (m->side2) (void)hipStreamDestroy(m->side2);
     }
@@ -284,6 +286,8 @@ void ws_layout(const aread_model* m, int64_t B, int n_seg, WsLayout* w) {
     w->slab_tgate = slab(1, m->gate_rows > 0 ? m->gate_rows : 1, 2 * E);
     w->rw_part = take(&o, tiles * 4 * ((int64_t)(2 * MAX_CROSS + 1) * D + 4));
     w->misc_part = take(&o, tiles * 4 * 1024);
+    w->cs_part_e = take(&o, tiles * m->ld_ge);
+    w->cs_part_t = take(&o, tiles * m->ld_gt);
     w->tf_sync = take(&o, 2 * (AREAD_MAX_LEVEL * AREAD_MAX_LAYER * MAX_SEG + 64));
     w->ab_sync = take(&o, AREAD_MAX_LAYER * 16 * MAX_SEG);      // arrival counters of k_act_bn_bwd: [layer][<= 16 column chunks][segment]
     w->tf_tags = o;

@@ -59,6 +59,10 @@ struct aread_model {
     mutable hipEvent_t ev[64] = {};
     mutable hipEvent_t ev_prep = nullptr;    // forward: the backward-only preparations (transposed weights, dgrad images) are done on the side stream
     mutable bool prep_pending = false;
+    mutable bool side2_pending = false;      // aread_backward left parameter-gradient work on side2: aread_join waits for it too
+    mutable hipEvent_t ev_join2 = nullptr;
+    mutable bool fwd_tail_deferred = false;  // fused step (async_tail bit 1): the forward left its loss / running-statistics tail to aread_backward
+    mutable const void* fwd_prepared = nullptr;   // aread_prepare queued the plan-independent side work of the next forward on this workspace
     mutable int n_ev = 0;
     mutable bool ab_tags_clean = false;    // k_act_bn_bwd's tags were zeroed by the last forward
     mutable bool bwd_tags_clean = false;   // the fused tower backward's hand-off tags were zeroed by the last forward and not used yet
@@ -74,6 +78,7 @@ struct WsLayout {                            // float offsets into the workspace
     int64_t active;                          // bytes region (as float offset): [n_level][MAX_SEG][MAX_TOWER]
     int64_t kact, seg_dom;                   // ints: active heads per seg, domain of each seg
     int64_t loss_part, gate_part, rw_part, misc_part;
+    int64_t cs_part_e, cs_part_t;            // per-tile column sums of the gate-logit gradients (gate bias gradients)
     int64_t tf_sync;                         // fused tower kernels: arrival counters [MAX_LEVEL*MAX_LAYER][MAX_SEG] x 2 (fwd, bwd) + error words
     int64_t tf_tags = -1, tf_tags_floats = 0, ab_tags_floats = 0;   // all tag_f / tag_b buffers, contiguous: zeroed by one memset per forward
     int64_t ab_sync = -1;         // k_act_bn_bwd arrival counters (-1: layout without them, e.g. the stand-alone MLP)
@@ -90,7 +95,10 @@ static inline KSplit wgrad_ksplit(int64_t rows, int G, int M, int N) {
     int tn = N > 32 ? 64 : (N > 16 ? 32 : 16);
     if (N > 64) tn = ((N + 95) / 96 * 96 < (N + 127) / 128 * 128) ? 96 : 128;
     const int64_t blocks_mn = (int64_t)G * ((M + 63) / 64) * ((N + tn - 1) / tn);
-    int64_t want = (768 + blocks_mn - 1) / blocks_mn;
+    // small weight gradients (towers, gates, heads) share ONE launch with a dozen others (k_gemm_bf3_rc_multi): ~128 workgroups
+    // each fill the chip together, and 5-6x fewer slabs to write and to reduce than a chip-filling split of every one of them
+    const int64_t target = (int64_t)G * M * N <= 32768 ? 128 : 768;
+    int64_t want = (target + blocks_mn - 1) / blocks_mn;
     const int64_t max_split = rows / TILE_M;
     if (want > max_split) want = max_split;
     if (want < 1) want = 1;

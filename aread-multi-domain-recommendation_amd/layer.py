@@ -137,20 +137,28 @@ class FeaturesEmbedding(nn.Module):
             self._bwd_ws = torch.empty(int(need), dtype=torch.uint8, device=x.device)
         return self._bwd_ws
 
-    def sort_lookups(self, x, sample_row=None):
-        """phase 1 of scatter_grad: depends only on the ids, can run on a side stream."""
+    def bwd_ws_bytes(self, x):
+        need = L.lib().aread_embed_bwd_ws_bytes(x.shape[0], x.shape[1], self.embed_dim)
+        if need < 0:
+            raise RuntimeError("aread_embed_bwd_ws_bytes failed")
+        return int(need)
+
+    def sort_lookups(self, x, sample_row=None, ws=None):
+        """phase 1 of scatter_grad: depends only on the ids, can run on a side stream (ws: a caller-owned workspace of
+        bwd_ws_bytes(x) bytes instead of the module's own, e.g. the prefetched batch of AREAD.prepare_batch)."""
         B, f_in = x.shape
         L.check(L.lib().aread_embed_bwd_sort(L.ptr(x), B, f_in, L.ptr(self._offsets_dev(x.device)),
                                              self.embedding_dict.weight.shape[0], self.embed_dim, self.one_hot_field_num,
                                              self.multi_hot_field_num, self.seq_maxlen, self._pool, L.ptr(sample_row),
-                                             L.ptr(self._ws_for(x)), L.stream()))
+                                             L.ptr(ws if ws is not None else self._ws_for(x)), L.stream()))
 
-    def reduce_sorted(self, x, dout, grad):
-        """phase 2 of scatter_grad: grad[g] += contributions, in the order fixed by sort_lookups."""
+    def reduce_sorted(self, x, dout, grad, ws=None, dout2=None):
+        """phase 2 of scatter_grad: grad[g] += contributions, in the order fixed by sort_lookups (dout2: a second addend of
+        the gradient, row for row)."""
         B, f_in = x.shape
         seq = self.seq_maxlen if self._pool != 0 else 1
-        L.check(L.lib().aread_embed_bwd_reduce(B, f_in, self.embed_dim, seq, L.ptr(dout), L.ptr(grad), L.ptr(self._ws_for(x)),
-                                               L.stream()))
+        L.check(L.lib().aread_embed_bwd_reduce2(B, f_in, self.embed_dim, seq, L.ptr(dout), L.ptr(dout2), L.ptr(grad),
+                                                L.ptr(ws if ws is not None else self._ws_for(x)), L.stream()))
 
     def forward(self, x, squeeze_dim=False, row_plan=None):
         """x: int32 [B, F_in] on the HIP device -> [B, output_dim0, E] (or [B, output_dim0*E])."""

@@ -46,6 +46,8 @@ def parse(argv=None):
                     help="GEMM arithmetic of the expert/tower forward+dgrad: exact fp32 MFMA or split-bf16 (3 products)")
     ap.add_argument("--no-route-prefetch", action="store_true", help="sharded table: route every batch inline (host read on the "
                     "critical path) instead of prefetching the next batch's routing during the current step")
+    ap.add_argument("--no-prefetch", action="store_true", help="eager step: row plan and index sort inside the step (A/B of "
+                    "AREAD.prepare_batch)")
     ap.add_argument("--step-only", action="store_true", help="profiling: run only the warm-up + timed steps (no roofline "
                     "micro-loops, no forward-only / fused-optimizer extras, no CPU baseline), so rocprofv3 sees the pure step")
     ap.add_argument("--kernels-only", action="store_true", help="profiling: one step to size the buffers, then only the "
@@ -258,6 +260,22 @@ def main():
         def after():
             pass
 
+        # eager launches: the batches are used where they lie in HBM (no copy into static tensors) and the ids-only stage of
+        # batch i+1 (row plan + index sort of the embedding backward: AREAD.prepare_batch, an input-pipeline stage like the
+        # sharded table's route prefetch) is issued on the model's prefetch stream right before step i, inside the timed
+        # region, once per step; two PreparedBatch buffers alternate
+        pipe = {"cur": None, "spare": None}
+
+        def eager_step(i):
+            xb, yb = batches[i % n_batches][:2]
+            cur = pipe["cur"]
+            if cur is None or cur.x is not xb:
+                cur = model.prepare_batch(xb, reuse=pipe["spare"])
+                pipe["spare"] = None
+            nxt = model.prepare_batch(batches[(i + 1) % n_batches][0], reuse=pipe["spare"]) if not args.no_prefetch else None
+            model.train_step(xb, yb, bufs, masks_dev=masks_dev, set_grads=False, prepared=cur if not args.no_prefetch else None)
+            pipe["spare"], pipe["cur"] = cur, nxt
+
     # ---- warm-up (also sizes the embedding-backward workspace) ---------------------------------------
     xs.copy_(batches[0][0]); ys.copy_(batches[0][1])
     log("first eager step")
@@ -286,6 +304,9 @@ def main():
 
     def run_one(i):
         cur["i"] = i
+        if graph is None and not use_dp:
+            eager_step(i)
+            return
         xb, yb = batches[i % n_batches][:2]
         xs.copy_(xb, non_blocking=True); ys.copy_(yb, non_blocking=True)
         if graph is not None:

@@ -102,6 +102,10 @@ int aread_embed_bwd_sort(const int32_t* x, int64_t B, int f_in, const int32_t* o
                          const int32_t* sample_row, void* ws, void* stream);
 int aread_embed_bwd_reduce(int64_t B, int f_in, int E, int seq_len, const float* dout, float* table_grad,
                            void* ws, void* stream);
+/* The same with the gradient given as the sum of two buffers (dout2 may be NULL): row r contributes dout[r] + dout2[r].
+ * aread_call.de_rw keeps the row-wise trunk's share of dL/de apart from the expert stack's. */
+int aread_embed_bwd_reduce2(int64_t B, int f_in, int E, int seq_len, const float* dout, const float* dout2, float* table_grad,
+                            void* ws, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Lookup routing for a row-sharded table (multi-GPU extension; no counterpart in the single-device
@@ -244,12 +248,29 @@ typedef struct aread_call {
      * aread_backward returns (stream order).  l2_table == NULL: nothing is launched. */
     const float* l2_table; int64_t l2_n; float l2_coef; int32_t l2_workgroups;
     float* l2_grad; float* l2_partial; float* l2_reg_out;
-    /* Optional (aread_backward, only together with l2_table): the dense L2 terms (aread_l2_dense: grads += 2*coef*w,
-     * l2_reg_out[0] += sum coef*w^2) issued on the internal side stream right behind the last parameter-gradient
-     * reduction instead of by the caller after the join.  l2_dense_coef: device vector like params. */
+    /* L2 coefficient per dense parameter (device vector like params; aread_model_l2_coef fills a host copy): read by
+     * aread_prepare for the dense L2 terms at the head of the step (init_grads below). */
     const float* l2_dense_coef;
+    /* aread_backward: non-zero = `grads` already holds an initial value (the fused step starts it from the dense L2 term,
+     * aread_l2_dense_init) and every parameter gradient is ADDED to it; 0 = the buffer is cleared first. */
+    int32_t grads_init;
+    /* Optional (aread_prepare): together with l2_dense_coef, the dense L2 terms at the head of the step on the side stream:
+     * init_grads[i] = 2*coef[i]*w[i] (written), init_reg_out[0] = sum coef*w^2 (257 floats).  Pass the same buffer as `grads`
+     * to aread_backward with grads_init = 1. */
+    float* init_grads; float* init_reg_out;
+    /* Optional (aread_backward): where the row-wise trunk backward (linear term, cross network, gate inputs) writes ITS share
+     * of dL/de_in, [plan.max_rows][D].  de_out then holds the expert stack's share only (gradient = de_out + de_rw; the
+     * embedding backward aread_embed_bwd_reduce2 adds them on the fly) and the first expert layer's dgrad no longer waits for
+     * the row-wise chain.  NULL: de_out holds the whole gradient. */
+    float* de_rw;
 } aread_call;
 
+/* Optional, before the row plan / gather of a step: queues the part of the forward's preparation that depends only on the
+ * parameters, the masks and the call's scalars (mask tables, pre-tiled weight images, hand-off tag memsets, probs memset,
+ * the backward's transposed weights) on the model's side stream, forked from `stream` at this point.  call_host->plan is
+ * not read.  The next aread_forward on the same workspace then skips it.  (The reference has no counterpart: it rebuilds
+ * its Python-side mask logic inside every forward, aread.py:263-322.) */
+int aread_prepare(const aread_model* m, const aread_call* call_host, void* stream);
 /* e_in: embedding output in plan order [plan.max_rows][D] (aread_embed_fwd with the plan's row_sample). */
 int aread_forward(const aread_model* m, const aread_call* call_host, const float* e_in, void* stream);
 /* Backward of the same call (the workspace must be untouched since aread_forward).
@@ -312,6 +333,12 @@ int aread_l2_dense(const float* params, const float* coef, int64_t n, float* gra
  * block to finish does the fixed-order sum of the block partials (a process-wide self-resetting ticket: one call at a time). */
 int aread_l2_dense_total(const float* params, const float* coef, int64_t n, float* grads, float* loss_out,
                          int accumulate, const float* loss_in, float* total_out, void* stream);
+/* The fused step's head: grads[i] = 2*coef[i]*w[i] (WRITTEN: the buffer the backward then adds every gradient to, see
+ * aread_call.grads_init) and reg_out[0] = sum_i coef[i]*w[i]^2 (257 floats, as loss_out above).  get_regularization_loss's
+ * dense half (layer.py:96-112) moved from the serial tail of the step to its start. */
+int aread_l2_dense_init(const float* params, const float* coef, int64_t n, float* grads, float* reg_out, void* stream);
+/* The fused step's last launch: reg[0] += reg_dense[0]; total[0] = loss[0] + reg[0]  (run.py:678 `loss = loss + reg`). */
+int aread_step_total(const float* loss, const float* reg_dense, float* reg, float* total, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Wide split-bf16 GEMM (csrc/gemm_wide.h): the kernel behind the expert / tower Linear layers of aread_forward /
