@@ -965,19 +965,8 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     // ---- side stream, batch A ------------------------------------------------------------------------------------------------
     x.st = x.side;
     AR_HIP(hipStreamWaitEvent(x.side, ev_b1, 0));      // (the side stream's first wait of this call: dz, dglog*, dH of the towers are final)
-    if (tail_deferred) TRY(forward_tail(x, tower_fused_ok(x)));
     if (!c->grads_init) AR_HIP(hipMemsetAsync(grads, 0, (size_t)m->n_params * sizeof(float), x.st));   // every reduction below ADDS to grads
-    // dcn = dz V[:, :D]
-    TRY(simple_gemm(x, ws + x.w.dz, m->ld_h, true, P + m->head_w, m->head_ld, false, ws + x.w.dcn, D, nullptr, (int)x.rows, D,
-                    m->n_heads, 0, 1));
-    if (m->gate_rows == 0) AR_HIP(hipMemsetAsync(ws + x.w.dq, 0, (size_t)x.rows * 2 * E * sizeof(float), x.st));
-    // gate-input gradients first: dq = dglogT Tw (tower gates) and deg = dglogE Gw (MMoE gates) feed the row-wise backward
-    if (m->gate_rows > 0)
-        TRY(simple_gemm(x, ws + x.w.dglogT, m->ld_gt, true, P + m->tgate_w, 2 * E, false, ws + x.w.dq, 2 * E, nullptr, (int)x.rows,
-                        2 * E, m->gate_rows, 0, 1));
-    TRY(simple_gemm(x, ws + x.w.dglogE, m->ld_ge, true, P + m->gate_w, D, false, ws + x.w.deg, D, nullptr, (int)x.rows, D,
-                    n_ge, 0, 1));
-    hipEvent_t ev_gates = x.m->ev[x.ev_next++ % (x.m->n_ev - 1)];
+    hipEvent_t ev_gates = x.m->ev[x.ev_next++ % (x.m->n_ev - 1)];   // side2's cue: behind ev_b1 and behind the gradient buffer's initialisation
     AR_HIP(hipEventRecord(ev_gates, x.side));
     TRY(flush_wgrads_range(x, 0, n_pend_a));             // head, tower and gate weight gradients: one launch
     x.st = main_st;
@@ -994,6 +983,16 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     {
         AR_HIP(hipStreamWaitEvent(rw_stream, ev_gates, 0));
         x.st = rw_stream;
+        // dcn = dz V[:, :D]; gate-input gradients dq = dglogT Tw (tower gates) and deg = dglogE Gw (MMoE gates): the row-wise
+        // backward's inputs, on ITS stream (the side stream carries the weight gradients at the same time)
+        TRY(simple_gemm(x, ws + x.w.dz, m->ld_h, true, P + m->head_w, m->head_ld, false, ws + x.w.dcn, D, nullptr, (int)x.rows, D,
+                        m->n_heads, 0, 1));
+        if (m->gate_rows == 0) AR_HIP(hipMemsetAsync(ws + x.w.dq, 0, (size_t)x.rows * 2 * E * sizeof(float), x.st));
+        if (m->gate_rows > 0)
+            TRY(simple_gemm(x, ws + x.w.dglogT, m->ld_gt, true, P + m->tgate_w, 2 * E, false, ws + x.w.dq, 2 * E, nullptr, (int)x.rows,
+                            2 * E, m->gate_rows, 0, 1));
+        TRY(simple_gemm(x, ws + x.w.dglogE, m->ld_ge, true, P + m->gate_w, D, false, ws + x.w.deg, D, nullptr, (int)x.rows, D,
+                        n_ge, 0, 1));
         RowwiseBwdP rb = {};
         rb.e = e_in; rb.xw = ws + x.w.xw; rb.dcn = ws + x.w.dcn; rb.dlin = ws + x.w.dlin; rb.dq = ws + x.w.dq; rb.deg = ws + x.w.deg;
         rb.lin_w = P + m->lin_w; rb.cn_w = P + m->cn_w; rb.cn_b = P + m->cn_b;
@@ -1049,6 +1048,7 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     TRY(flush_wgrads_range(x, n_pend_a, x.n_pend));
     x.n_pend = 0;
     TRY(flush_reductions(x));
+    if (tail_deferred) TRY(forward_tail(x, tower_fused_ok(x)));      // loss value + running statistics: nothing waits for them before the join
     x.st = main_st;
     // de_out (and de_rw) are complete on the main stream here; the parameter gradients complete on the two side streams
     // (side: weight / bias / BatchNorm gradients; side2: row-wise trunk, group embedding, gate biases, head tails).

@@ -1040,11 +1040,19 @@ __global__ __launch_bounds__(256) void k_grp_bwd(const float* dgrp_seg, float* d
         const int t = i / E, c = i - t * E;
         float acc = 0.f;
         if (mp.mode == 0)
-            for (int seg = 0; seg < r.n_seg; ++seg) {
-                if (r.seg_count[seg] == 0 || !active_level(mp, 0)[seg * MAX_TOWER + t]) continue;
-                const float s = dgrp_seg[(int64_t)seg * E + c];
-                const int n0 = mp.n0act[seg];
-                acc += n0 > 1 ? s / (float)n0 : s;
+            for (int s0 = 0; s0 < r.n_seg; s0 += 8) {              // (loads of eight segments in flight, sums in segment order)
+                float sv[8]; int n0[8]; bool on[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int seg = s0 + u;
+                    const bool in = seg < r.n_seg;
+                    on[u] = in && r.seg_count[seg] != 0 && active_level(mp, 0)[seg * MAX_TOWER + t] != 0;
+                    sv[u] = dgrp_seg[(int64_t)(in ? seg : 0) * E + c];
+                    n0[u] = mp.n0act[in ? seg : 0];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (on[u]) acc += n0[u] > 1 ? sv[u] / (float)n0[u] : sv[u];
             }
         dgroup[i] += acc;
     }
@@ -1067,14 +1075,26 @@ __global__ __launch_bounds__(256) void k_bn_running(const BnRunAllP a) {
     if (c >= p.ncols) return;
     float rm = p.rmean[c], rv = p.rvar[c];
     int n_upd = 0;
-    for (int seg = 0; seg < a.r.n_seg; ++seg) {
-        const int cnt = a.r.seg_count[seg];
-        if (cnt <= 1) continue;
-        if (p.level >= 0 && !active_level(a.mp, p.level)[seg * MAX_TOWER + c / p.h]) continue;
-        const int64_t o = (int64_t)seg * p.ncols + c;
-        rm = (1.0f - BN_MOMENTUM) * rm + BN_MOMENTUM * p.mean[o];
-        rv = (1.0f - BN_MOMENTUM) * rv + BN_MOMENTUM * (p.var[o] * ((float)cnt / (float)(cnt - 1)));
-        ++n_upd;
+    // the EMA is a serial recurrence in domain order, its inputs are not: eight segments' loads are issued together (the
+    // version with one dependent round trip per segment took 30 us for 25 segments)
+    for (int s0 = 0; s0 < a.r.n_seg; s0 += 8) {
+        int cnt[8]; float mu[8], va[8]; bool on[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int seg = s0 + u;
+            const bool in = seg < a.r.n_seg;
+            cnt[u] = in ? a.r.seg_count[seg] : 0;
+            on[u] = in && (p.level < 0 || active_level(a.mp, p.level)[seg * MAX_TOWER + c / p.h] != 0);
+            const int64_t o = (int64_t)(in ? seg : 0) * p.ncols + c;
+            mu[u] = p.mean[o]; va[u] = p.var[o];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (cnt[u] <= 1 || !on[u]) continue;
+            rm = (1.0f - BN_MOMENTUM) * rm + BN_MOMENTUM * mu[u];
+            rv = (1.0f - BN_MOMENTUM) * rv + BN_MOMENTUM * (va[u] * ((float)cnt[u] / (float)(cnt[u] - 1)));
+            ++n_upd;
+        }
     }
     p.rmean[c] = rm; p.rvar[c] = rv;
     if (c % p.h == 0) p.nbt[c / p.h] += n_upd;

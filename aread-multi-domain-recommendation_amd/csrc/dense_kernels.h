@@ -530,7 +530,18 @@ __global__ __launch_bounds__(64) void k_loss_finish(const float* loss_part, cons
     if (seg < r.n_seg) {
         const int cnt = r.seg_count[seg];
         const int t0 = r.seg_start[seg] / TILE_M, nt = (cnt + TILE_M - 1) / TILE_M;
-        for (int t = 0; t < nt * SUB; ++t) bag += loss_part[t0 * SUB + t];
+        // (same summation order as a plain loop; eight independent loads in flight instead of one dependent chain)
+        const float* lp = loss_part + t0 * SUB;
+        const int n = nt * SUB;
+        int t = 0;
+        for (; t + 8 <= n; t += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = lp[t + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) bag += v[u];
+        }
+        for (; t < n; ++t) bag += lp[t];
         loss_out[1 + seg] = bag;
         bag *= seg_weight ? seg_weight[seg] : 1.f;
     }
