@@ -51,11 +51,6 @@ _SIGS = {
     "aread_debug_set": (C.c_int, [C.c_char_p, C.c_int]),
     "aread_debug_get": (C.c_longlong, [C.c_char_p]),
     "aread_debug_phase_times": (C.c_int, [C.c_void_p, C.c_int]),
-    "aread_debug_gemm_stamps": (C.c_int, [C.c_void_p, C.c_int]),
-    "aread_wimg_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
-    "aread_wimg_prepare": (C.c_int, [f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, vp, vp]),
-    "aread_gemm_bf16x3_wide": (C.c_int, [f32p, C.c_int64, C.c_int64, vp, f32p, C.c_int64, C.c_int64, f32p, C.c_int64, C.c_int,
-                                         C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "aread_gemm": (C.c_int, [f32p, C.c_int64, C.c_int64, C.c_int, f32p, C.c_int64, C.c_int64, C.c_int, f32p, C.c_int64,
                              C.c_int64, f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
 }

@@ -94,18 +94,10 @@ static const uint8_t* level_active(const Ctx& x, int level) {
     return level >= 0 ? x.mp.active + (size_t)level * MAX_SEG * MAX_TOWER : nullptr;
 }
 
-// ---- pre-tiled split-bf16 weight images for the wide GEMM (gemm_wide.h) ------------------------------------------
+// ---- pre-tiled split-bf16 weight images of the tower layers (gemm_wide.h): read by the fused tower kernels ---------------
 static bool layer_one_group(const LayerL& L) { return (L.in_gs == 0 && L.G > 1) || L.G == 1; }
-static WImgDesc wimg_desc(const Ctx& x, const LayerL& L, const LayerWs& lw, bool dgrad) {
-    const bool one = layer_one_group(L);
-    const int N = dgrad ? L.in_dim : (one ? L.ncols : L.out_dim), K = dgrad ? (one ? L.ncols : L.out_dim) : L.in_dim;
-    WImgDesc w;
-    w.img = (const __bf16*)(x.ws + (dgrad ? lw.wimg_d : lw.wimg_f));
-    w.NF = wide_nf(N); w.NT = (N + 32 * w.NF - 1) / (32 * w.NF); w.KS = (K + 31) / 32;
-    return w;
-}
-// which == 0: forward images, 1: dgrad images.  One launch for every Linear of the model's stacks, on x.st.
-static int prepare_wimg(Ctx& x, int which, bool towers_only = false) {
+// which == 0: forward images, 1: dgrad images.  One launch for every Linear of the tower stacks, on x.st.
+static int prepare_wimg(Ctx& x, int which) {
     const aread_model* m = x.m;
     WPrepAllP a = {};
     auto add = [&](const LayerL& L, const LayerWs& lw) {
@@ -117,29 +109,12 @@ static int prepare_wimg(Ctx& x, int which, bool towers_only = false) {
         else { d.N = L.in_dim; d.K = out; d.sn = 1; d.sk = L.in_dim; d.img = (__bf16*)(x.ws + lw.wimg_d); }
         d.NF = wide_nf(d.N); d.NT = (d.N + 32 * d.NF - 1) / (32 * d.NF); d.KS = (d.K + 31) / 32;
     };
-    if (!towers_only)
-        for (int j = 0; j < m->experts.n_layers; ++j) add(m->experts.L[j], x.w.ex[j]);
     if (!m->is_mlp)
         for (int l = 0; l < m->cfg.n_level; ++l)
             for (int j = 0; j < m->towers[l].n_layers; ++j) add(m->towers[l].L[j], x.w.tw[l][j]);
     AR_CHECK_ARG(a.n <= WPREP_MAX, "too many layers for one weight-image launch");
     return launch_prep_wimg(a, x.st);
 }
-static int g_wide_mode = -1;      // AREAD_WIDE: 0 = 64-row kernels everywhere (default: measured equal or faster in the step), 1 = wide kernel for the experts, 2 = for every layer
-static bool wide_any() {
-    if (g_wide_mode < 0) {
-        const char* e = getenv("AREAD_WIDE");
-        g_wide_mode = e ? atoi(e) : 0;
-    }
-    return g_wide_mode > 0;
-}
-static bool use_wide(const Ctx& x, const LayerL& L) {
-    wide_any();
-    if (x.m->cfg.precision != 1 || g_wide_mode == 0) return false;
-    if (L.in_dim < 32 || L.out_dim < 32) return false;                    // rows of both the forward (K = in) and the dgrad (K = out) operand
-    return g_wide_mode >= 2 || L.stack == 0;
-}
-
 // ---- one MLP layer forward: H = in W^T + b (statistics in the epilogue) ; finalize ; BN+ReLU+dropout ----
 static int layer_fwd(Ctx& x, const LayerL& L, const LayerWs& lw, const float* in, int level) {
     const bool shared = L.in_gs == 0 && L.G > 1;
@@ -153,8 +128,7 @@ static int layer_fwd(Ctx& x, const LayerL& L, const LayerWs& lw, const float* in
     g.gate_axis = 1; g.tile_seg = x.r.tile_seg; g.tile_valid = x.r.tile_valid;
     g.active = (level >= 0 && g.G > 1) ? level_active(x, level) : nullptr; g.active_ld = MAX_TOWER;
     if (x.c->train) { g.stat_part = x.ws + lw.part; g.stat_ld = L.ncols; }
-    if (use_wide(x, L)) TRY(launch_gemm_bf3w(g, wimg_desc(x, L, lw, false), x.st));
-    else if (x.m->cfg.precision == 1) TRY(launch_gemm_bf3(g, x.st));
+    if (x.m->cfg.precision == 1) TRY(launch_gemm_bf3(g, x.st));
     else TRY(launch_gemm(g, true, true, x.st));
     BnActP a = {};
     a.H = x.ws + lw.H; a.Act = x.ws + lw.Act; a.part = x.ws + lw.part;
@@ -524,7 +498,7 @@ static int forward_prep(Ctx& x, bool with_plan_independent_tail) {
     mp.seg_dom = (int32_t*)(ws + x.w.seg_dom); mp.grp = ws + x.w.grp;
     const bool fused_towers = tower_fused_ok(x);
     LAUNCH(k_mask_prep, dim3(1), dim3(256), mp);
-    if (cfg.precision == 1 && fused_towers && !wide_any()) TRY(prepare_wimg(x, 0));   // (the fused tower kernel reads them after the join)
+    if (cfg.precision == 1 && fused_towers) TRY(prepare_wimg(x, 0));   // (the fused tower kernel reads them after the join)
     if (g_fused_act_bn < 0) { const char* e = getenv("AREAD_FUSED_ACT_BN"); g_fused_act_bn = e ? atoi(e) : 1; }
     m->ab_tags_clean = false;
     if (fused_towers || g_fused_act_bn > 0) {
@@ -541,8 +515,7 @@ static int forward_prep(Ctx& x, bool with_plan_independent_tail) {
         m->prep_pending = false;
         if (c->train && cfg.precision == 1) {
             TRY(transpose_weights(x));
-            if (wide_any()) TRY(prepare_wimg(x, 1));
-            else if (tower_fused_bwd_ok(x)) TRY(prepare_wimg(x, 1, true));   // dgrad images of the tower layers
+            if (tower_fused_bwd_ok(x)) TRY(prepare_wimg(x, 1));   // dgrad images of the tower layers
             AR_HIP(hipEventRecord(m->ev_prep, x.st));
             m->prep_pending = true;
         }
@@ -606,7 +579,6 @@ extern "C" int aread_forward(const aread_model* m, const aread_call* c, const fl
     const bool prepared = m->fwd_prepared == c->ws && c->ws != nullptr;      // aread_prepare already queued the plan-independent side work
     m->fwd_prepared = nullptr;
     const bool fused_towers = tower_fused_ok(x);
-    if (cfg.precision == 1 && wide_any()) TRY(prepare_wimg(x, 0));    // forward weight images: the wide expert GEMMs need them first
     // 4. experts FIRST on the main stream (issue order = the order a captured graph schedules independent branches): the
     // side work below forks from the point before them
     hipEvent_t ev_f0 = x.m->ev[x.ev_next++ % (x.m->n_ev - 1)];
@@ -643,8 +615,7 @@ extern "C" int aread_forward(const aread_model* m, const aread_call* c, const fl
             m->prep_pending = false;
             if (c->train && cfg.precision == 1) {
                 TRY(transpose_weights(x));
-                if (wide_any()) TRY(prepare_wimg(x, 1));
-                else if (tower_fused_bwd_ok(x)) TRY(prepare_wimg(x, 1, true));   // dgrad images of the tower layers
+                if (tower_fused_bwd_ok(x)) TRY(prepare_wimg(x, 1));   // dgrad images of the tower layers
                 AR_HIP(hipEventRecord(m->ev_prep, x.side));
                 m->prep_pending = true;
             }
@@ -823,8 +794,7 @@ static int layer_bwd(Ctx& x, const LayerL& L, const LayerWs& lw, const float* in
         g.M = (int)x.rows; g.N = L.in_dim; g.K = L.out_dim; g.G = L.G; g.accumulate = accumulate_d_in;
         if (shared || L.G == 1) { g.K = L.ncols; g.G = 1; g.a_gs = 0; g.b_gs = 0; g.c_gs = 0; }
         g.gate_axis = 1; g.tile_seg = x.r.tile_seg; g.tile_valid = x.r.tile_valid;
-        if (use_wide(x, L)) TRY(launch_gemm_bf3w(g, wimg_desc(x, L, lw, true), x.st));
-        else if (x.m->cfg.precision == 1) {         // k-contiguous B from the transposed weight copy [g][in][out]
+        if (x.m->cfg.precision == 1) {         // k-contiguous B from the transposed weight copy [g][in][out]
             g.B = x.ws + lw.wT;
             g.ldb = (shared || L.G == 1) ? L.ncols : L.out_dim;
             g.b_gs = (shared || L.G == 1) ? 0 : (int64_t)L.in_dim * L.out_dim;
@@ -1066,7 +1036,6 @@ extern "C" int aread_debug_set(const char* key, int value) {
     else if (!strcmp(key, "fused_towers_bwd")) g_fused_bwd = value;
     else if (!strcmp(key, "fused_act_bn")) g_fused_act_bn = value;
     else if (!strcmp(key, "plan_single")) g_plan_single = value;
-    else if (!strcmp(key, "wide_gemm")) g_wide_mode = value;
     else if (!strcmp(key, "tf_stamps")) g_tf_stamps = value;
     else if (!strcmp(key, "phase_events")) g_phase_on = value;
     else AR_CHECK_ARG(false, "aread_debug_set: unknown key %s", key);
@@ -1149,8 +1118,7 @@ extern "C" int aread_mlp_forward(const aread_model* m, const aread_mlp_call* c, 
     float* ws = x.ws;
     const int in = m->mlp_in, nl = m->experts.n_layers, last = m->h_last;
     LAUNCH(k_pad_rows, dim3(cdiv(x.rows * in, 256)), dim3(256), xin, (int64_t)in, ws + x.w.In[0], (int64_t)in, in, c->B, x.rows);
-    if (m->cfg.precision == 1 && wide_any()) TRY(prepare_wimg(x, 0));
-    if (c->train && m->cfg.precision == 1) { TRY(transpose_weights(x)); if (wide_any()) TRY(prepare_wimg(x, 1)); }   // for the dgrad of aread_mlp_backward
+    if (c->train && m->cfg.precision == 1) TRY(transpose_weights(x));   // for the dgrad of aread_mlp_backward
     TRY(stack_fwd(x, m->experts, x.w.ex, ws + x.w.In[0], -1));
     const float* act = ws + x.w.ex[nl - 1].Act;
     if (m->mlp_out_layer) {

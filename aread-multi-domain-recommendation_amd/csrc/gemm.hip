@@ -156,51 +156,7 @@ extern "C" int aread_gemm_bf16x3(const float* A, int64_t lda, int64_t a_gs, cons
     return launch_gemm_bf3(p, (hipStream_t)stream);
 }
 
-// ---- wide split-bf16 GEMM (gemm_wide.h) ----------------------------------------------------------------------------
-int launch_gemm_bf3w(const GemmP& p_in, const WImgDesc& w, hipStream_t st) {
-    GemmP p = p_in;
-    static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("AREAD_GEMM_DBG"); dbg = e ? atoi(e) : 0; }
-    p.dbg = dbg;
-    AR_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0 && p.G > 0, "gemm_bf3w: empty problem");
-    AR_CHECK_ARG(p.lda % 4 == 0 && p.a_gs % 4 == 0 && p.ldc % 4 == 0 && p.c_gs % 4 == 0 && p.N % 4 == 0 && p.bias_gs % 4 == 0,
-                 "gemm_bf3w: N, leading dimensions and group strides must be multiples of 4");
-    AR_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.C & 15) == 0 && ((uintptr_t)w.img & 15) == 0 &&
-                 ((uintptr_t)p.bias & 15) == 0, "gemm_bf3w: operands must be 16-byte aligned");
-    AR_CHECK_ARG(p.gate_axis == 0 || (p.gate_axis == 1 && p.tile_seg != nullptr && p.tile_valid != nullptr),
-                 "gemm_bf3w: only row-tile gating is supported");
-    AR_CHECK_ARG(!p.stat_part || (p.gate_axis == 1 && p.stat_ld % 2 == 0 && ((uintptr_t)p.stat_part & 15) == 0),
-                 "gemm_bf3w: the statistics epilogue needs the row plan");
-    AR_CHECK_ARG(w.NT == (p.N + 32 * w.NF - 1) / (32 * w.NF) && w.KS == (p.K + 31) / 32, "gemm_bf3w: weight image does not match N/K");
-    const dim3 grid(w.NT, cdiv(p.M, 128), p.G);
-    // two workgroups per CU with the double-buffered A image, three with the single one: pick what keeps the launch in one
-    // residency round of the 256 CUs
-    const int tiles = (int)(grid.x * grid.y * grid.z);
-    bool adb = !(tiles > 512 && tiles <= 768);
-    if (dbg & 2) adb = false;
-    if (dbg & 4) adb = true;
-#define GW_LAUNCH(NF_)                                                                                      \
-    do {                                                                                                    \
-        if (adb) hipLaunchKernelGGL((k_gemm_bf3w<NF_, true>), grid, dim3(GEMM_THREADS), 0, st, p, w);       \
-        else hipLaunchKernelGGL((k_gemm_bf3w<NF_, false>), grid, dim3(GEMM_THREADS), 0, st, p, w);          \
-    } while (0)
-    switch (w.NF) {
-        case 2: GW_LAUNCH(2); break;
-        case 3: GW_LAUNCH(3); break;
-        case 4: GW_LAUNCH(4); break;
-        default: AR_CHECK_ARG(false, "gemm_bf3w: NF=%d", w.NF);
-    }
-#undef GW_LAUNCH
-    AR_LAUNCH_CHECK();
-    return AREAD_OK;
-}
-
-extern "C" int aread_debug_gemm_stamps(unsigned long long* host_out, int n) {
-    if (!host_out || n <= 0 || n > 4 * 256) return AREAD_ERR_ARG;
-    AR_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gw_stamps), (size_t)n * sizeof(unsigned long long)));
-    return AREAD_OK;
-}
-
+// ---- pre-tiled split-bf16 weight images (gemm_wide.h) --------------------------------------------------------------------
 int launch_prep_wimg(const WPrepAllP& a, hipStream_t st) {
     if (a.n <= 0) return AREAD_OK;
     int mx = 1;
@@ -212,36 +168,4 @@ int launch_prep_wimg(const WPrepAllP& a, hipStream_t st) {
     hipLaunchKernelGGL(k_prep_wimg, dim3(mx, a.n), dim3(256), 0, st, a);
     AR_LAUNCH_CHECK();
     return AREAD_OK;
-}
-
-extern "C" int64_t aread_wimg_bytes(int N, int K, int G) {
-    if (N <= 0 || K <= 0 || G <= 0) return -1;
-    return wimg_elems(G, N, K, wide_nf(N)) * 2;
-}
-
-extern "C" int aread_wimg_prepare(const float* W, int64_t w_gs, int64_t w_sn, int64_t w_sk, int N, int K, int G, void* img,
-                                  void* stream) {
-    AR_CHECK_ARG(W && img && N > 0 && K > 0 && G > 0, "aread_wimg_prepare: bad arguments");
-    AR_CHECK_ARG(((uintptr_t)img & 255) == 0, "aread_wimg_prepare: the image must be 256-byte aligned");
-    WPrepAllP a = {};
-    a.n = 1;
-    WPrepOne& d = a.d[0];
-    d.W = W; d.img = (__bf16*)img; d.G = G; d.N = N; d.K = K; d.NF = wide_nf(N);
-    d.NT = (N + 32 * d.NF - 1) / (32 * d.NF); d.KS = (K + 31) / 32; d.gs = w_gs; d.sn = w_sn; d.sk = w_sk;
-    return launch_prep_wimg(a, (hipStream_t)stream);
-}
-
-extern "C" int aread_gemm_bf16x3_wide(const float* A, int64_t lda, int64_t a_gs, const void* img, float* C, int64_t ldc,
-                                      int64_t c_gs, const float* bias, int64_t bias_gs, int M, int N, int K, int G,
-                                      int accumulate, void* stream) {
-    AR_CHECK_ARG(A && img && C, "aread_gemm_bf16x3_wide: null pointer");
-    GemmP p = {};
-    p.A = A; p.lda = lda; p.a_gs = a_gs;
-    p.C = C; p.ldc = ldc; p.c_gs = c_gs;
-    p.bias = bias; p.bias_gs = bias_gs;
-    p.M = M; p.N = N; p.K = K; p.G = G;
-    p.accumulate = accumulate;
-    WImgDesc w;
-    w.img = (const __bf16*)img; w.NF = wide_nf(N); w.NT = (N + 32 * w.NF - 1) / (32 * w.NF); w.KS = (K + 31) / 32;
-    return launch_gemm_bf3w(p, w, (hipStream_t)stream);
 }

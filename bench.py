@@ -404,7 +404,7 @@ def main():
         return
     # ---- per-kernel rooflines, live HIP-event timing on the launch stream ------------------------------------------------
     # `roofline` is the DOMINANT kernel of the step: the split-bf16 GEMM family (k_gemm_bf3 forward/dgrad + k_gemm_bf3_rc weight
-    # gradients) takes the largest share of the step's kernel time (profiles/r02_kernel_stats_step.txt); its largest member, the
+    # gradients) takes the largest share of the step's kernel time (profiles/r03_kernel_stats_step_only_eager.txt); its largest member, the
     # expert layer-1 forward GEMM, is reported against the dense bf16 MFMA peak.  The other entries are extra.
     gemm = measure_gemm_kernel(model, bufs, L, B, args.precision)
     wgrad = measure_wgrad_kernel(model, bufs, L, B, args.precision)
@@ -443,6 +443,9 @@ def main():
         if args.precision == "bf16x3":
             out["tower_kernels"] = measure_tower_kernels(model, batches, bufs, masks_dev, B, L)
         out["forward_only"] = measure_forward_only(model, batches, bufs, masks_dev, B)      # BASELINE configs[1]
+        if args.workload == "amazon":
+            single = measure_dropin(model, masks, spec, B, synth, rng)                      # the reference's own loop body, nn.Module API
+            out["forward_eval"], out["dropin_step"] = single["forward_eval"], single["dropin_step"]
         # beyond the metric: the same step WITH the optimizer, fused (modifies the parameters: runs last)
         out["train_step_with_fused_adam"] = measure_fused_adam(model, batches, masks_dev, B, L)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -620,6 +623,66 @@ def measure_forward_only(model, batches, bufs, masks_dev, B, steps=50):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     return {"ms_per_step": round(dt * 1e3, 4), "samples_per_s": round(B / dt, 1), "mode": "train-mode forward + loss, eager"}
+
+
+def measure_dropin(model, masks, spec, B, synth, rng, steps=30):
+    """The reference-API path (what run.py calls, unchanged): single-domain batches of B samples through the nn.Module.
+      forward_eval: Run.test's body (run.py:712-763): model.eval(); model(X, mode='domain_with_mask', domain_i=d) under no_grad;
+      dropin_step : the training closure (run.py:668-682): model(X, mode='domain_mask_bagging', domain_i=d), BCELoss per head,
+                    get_regularization_loss, zero_grad, backward, optimizer.step() -- with torch.optim.Adam over
+                    model.parameters() (table + 298 dense tensors) and with aread_amd.Adam (two fused launches).
+    Runs after the timed region (the optimizers move the parameters)."""
+    import aread_amd
+    model.domain_mask = [[m if isinstance(m, torch.Tensor) else torch.tensor(np.asarray(m), dtype=torch.bool, device="cuda") for m in mk]
+                         for mk in masks]
+    batches = []
+    for d in (3, 6, 12):
+        x, y = synth.amazon_batch(spec, rng, B, domain=d)
+        batches.append((d, torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()))
+    out = {}
+    model.eval()
+    with torch.no_grad():
+        for i in range(5):
+            model(batches[i % 3][1], mode="domain_with_mask", domain_i=batches[i % 3][0])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            model(batches[i % 3][1], mode="domain_with_mask", domain_i=batches[i % 3][0])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    out["forward_eval"] = {"ms_per_batch": round(dt * 1e3, 4), "samples_per_s": round(B / dt, 1),
+                           "what": f"model.eval(); model(X, mode='domain_with_mask', domain_i=d), one domain, B={B} (run.py:712-763)"}
+    model.train()
+    crit = torch.nn.BCELoss()
+    hyper = dict(lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-8)
+    res = {}
+    for name in ("torch.optim.Adam", "aread_amd.Adam"):
+        opt = torch.optim.Adam(model.parameters(), **hyper) if name == "torch.optim.Adam" else aread_amd.Adam(model, **hyper)
+
+        def one(i):
+            d, X, y = batches[i % 3]
+            preds = model(X, mode="domain_mask_bagging", domain_i=d)
+            loss = sum(crit(p, y) for p in preds.unbind(0)) / preds.shape[0] + model.get_regularization_loss(device="cuda")
+            model.zero_grad()
+            loss.backward()
+            opt.step()
+            return loss
+        for i in range(4):
+            one(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            last = one(i)
+        float(last)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        res[name] = {"ms_per_step": round(dt * 1e3, 4), "samples_per_s": round(B / dt, 1)}
+        del opt
+        model.zero_grad(set_to_none=True)
+        torch.cuda.empty_cache()
+    out["dropin_step"] = {"what": f"run.py:668-682 unchanged on the nn.Module API: single-domain batch B={B}, fwd + per-head BCE + "
+                                  "get_regularization_loss + backward + optimizer.step()", **res}
+    return out
 
 
 def measure_fused_adam(model, batches, masks_dev, B, L, steps=30):

@@ -316,9 +316,6 @@ long long aread_debug_get(const char* key);
 /* Diagnostics: after aread_debug_set("phase_events", 1) the forward / backward record events at their phase boundaries on
  * the caller's stream; this returns the elapsed GPU time (ms) between consecutive boundaries of the last call. */
 int aread_debug_phase_times(float* out_ms, int n);
-/* Diagnostics: with AREAD_GEMM_DBG=1 in the environment the wide split-bf16 GEMM stamps s_memrealtime (100 MHz) at the k-step
- * phase boundaries of four of its workgroups; copies n <= 1024 stamps ([4 workgroups][256]) of the last launch to the host. */
-int aread_debug_gemm_stamps(unsigned long long* host_out, int n);
 /* Makes `stream` wait for the model's internal side stream (see aread_call.async_tail). */
 int aread_join(const aread_model* m, void* stream);
 /* Dense L2 terms: loss_out[0] (+)= sum_i coef[i]*w[i]^2, grads[i] += 2*coef[i]*w[i] (grads may be NULL).
@@ -339,22 +336,6 @@ int aread_l2_dense_total(const float* params, const float* coef, int64_t n, floa
 int aread_l2_dense_init(const float* params, const float* coef, int64_t n, float* grads, float* reg_out, void* stream);
 /* The fused step's last launch: reg[0] += reg_dense[0]; total[0] = loss[0] + reg[0]  (run.py:678 `loss = loss + reg`). */
 int aread_step_total(const float* loss, const float* reg_dense, float* reg, float* total, void* stream);
-
-/* ---------------------------------------------------------------------------------------------
- * Wide split-bf16 GEMM (csrc/gemm_wide.h): the kernel behind the expert / tower Linear layers of aread_forward /
- * aread_backward (MultiLayerPerceptron, model/layer.py:203-229; aread.py:150-151), exposed for tests and bench.py.
- *   C[g][m][n] (+)= sum_k A[g*a_gs + m*lda + k] * W(g, n, k) (+ bias[g*bias_gs + n]),  hi*hi + hi*lo + lo*hi on
- *   v_mfma_f32_16x16x32_bf16 with fp32 accumulation, 128-row tiles.
- * The weight operand is a pre-tiled split-bf16 image written once per parameter update by aread_wimg_prepare from
- * W(g, n, k) = W[g*w_gs + n*w_sn + k*w_sk] (forward: w_sn = K, w_sk = 1; dgrad view of a [out, in] weight: w_sn = 1,
- * w_sk = in); img: aread_wimg_bytes(N, K, G) bytes, 256-byte aligned.  N, lda, ldc and the group strides must be
- * multiples of 4.
- * ------------------------------------------------------------------------------------------- */
-int64_t aread_wimg_bytes(int N, int K, int G);
-int aread_wimg_prepare(const float* W, int64_t w_gs, int64_t w_sn, int64_t w_sk, int N, int K, int G, void* img,
-                       void* stream);
-int aread_gemm_bf16x3_wide(const float* A, int64_t lda, int64_t a_gs, const void* img, float* C, int64_t ldc, int64_t c_gs,
-                           const float* bias, int64_t bias_gs, int M, int N, int K, int G, int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused optimizer.  torch.optim.Adam as the reference configures it (run.py:830-831: lr 1e-3,

@@ -113,61 +113,3 @@ def test_gemm_bf16x3_row_contiguous(M, N, K, G):
                                          M, N, K, G, 0, L.stream()))
     torch.cuda.synchronize()
     np.testing.assert_array_equal(C2.cpu().numpy()[:, :, :N], np.einsum("gkm,gkn->gmn", ai[:, :, :M], bi[:, :, :N]))
-
-
-def _wide(a, b, bias, accumulate=False, C0=None, dgrad_view=False):
-    """C = a . b^T through aread_wimg_prepare + aread_gemm_bf16x3_wide.  a: [G, M, K], b: [G, N, K] (or, with
-    dgrad_view, the weight as torch stores it for the product a . W: W [G, K, N])."""
-    from aread_amd import _lib as L
-    G, M, K = a.shape
-    N = b.shape[2] if dgrad_view else b.shape[1]
-    pad = lambda n: (n + 3) // 4 * 4
-    lda = max(pad(K), 32)                                               # the wide kernel loads whole 32-float row pieces
-    A = np.zeros((G, M, lda), np.float32); A[:, :, :K] = a
-    ldc = pad(N) + 4
-    C = torch.full((G, M, ldc), 7.0, device="cuda") if C0 is None else torch.from_numpy(C0).cuda()
-    Ad, Bd = torch.from_numpy(A).cuda(), torch.from_numpy(np.ascontiguousarray(b)).cuda()
-    bd = None if bias is None else torch.from_numpy(bias).cuda()
-    img = torch.empty(L.lib().aread_wimg_bytes(N, K, G), dtype=torch.uint8, device="cuda")
-    if dgrad_view:      # W(g, n, k) = W[g][k][n]
-        L.check(L.lib().aread_wimg_prepare(L.ptr(Bd), K * N, 1, N, N, K, G, L.ptr(img), L.stream()))
-    else:
-        L.check(L.lib().aread_wimg_prepare(L.ptr(Bd), N * K, K, 1, N, K, G, L.ptr(img), L.stream()))
-    L.check(L.lib().aread_gemm_bf16x3_wide(L.ptr(Ad), lda, M * lda, L.ptr(img), L.ptr(C), ldc, M * ldc, L.ptr(bd),
-                                           N if bias is not None else 0, M, N, K, G, int(accumulate), L.stream()))
-    torch.cuda.synchronize()
-    return C.cpu().numpy()
-
-
-@pytest.mark.parametrize("M,N,K,G", [(64, 16, 32, 1), (200, 92, 64, 1), (130, 12, 288, 1), (8192, 1024, 288, 1), (9728, 288, 1024, 1),
-                                       (1000, 128, 256, 4), (300, 8, 16, 12), (77, 40, 44, 3), (9728, 64, 128, 4), (192, 96, 33, 2)])
-def test_gemm_bf16x3_wide(M, N, K, G):
-    """128-row-tile split-bf16 GEMM with pre-tiled weight images (LDS-DMA): ~1e-6 relative error against float64, nothing
-    written outside [M, N], ragged M / N / K edges."""
-    rng = np.random.default_rng(M + N + K + G)
-    a = rng.standard_normal((G, M, K)).astype(np.float32)
-    b = rng.standard_normal((G, N, K)).astype(np.float32)
-    bias = rng.standard_normal((G, N)).astype(np.float32)
-    C = _wide(a, b, bias)
-    ref = np.einsum("gmk,gnk->gmn", a.astype(np.float64), b.astype(np.float64)) + bias[:, None, :]
-    err = np.abs(C[:, :, :N] - ref).max() / np.abs(ref).max()
-    assert err < 2e-5, err
-    assert np.sqrt(((C[:, :, :N] - ref) ** 2).mean()) / np.sqrt((ref ** 2).mean()) < 1e-5
-    assert (C[:, :, N:] == 7.0).all()
-
-
-def test_gemm_bf16x3_wide_exact_integers_accumulate_and_dgrad_view():
-    """small integers are exact in bf16: asymmetric operands pin the fragment / accumulator layout bit for bit (a swapped
-    row/column map or k order cannot pass); accumulate adds onto C; the dgrad view reads the weight transposed."""
-    rng = np.random.default_rng(5)
-    G, M, N, K = 2, 200, 72, 100
-    a = rng.integers(-3, 4, (G, M, K)).astype(np.float32)
-    b = rng.integers(-3, 4, (G, N, K)).astype(np.float32)
-    ldc = N + 4
-    C0 = rng.integers(-5, 5, (G, M, ldc)).astype(np.float32)
-    C = _wide(a, b, None, accumulate=True, C0=C0.copy())
-    ref = C0.copy(); ref[:, :, :N] += np.einsum("gmk,gnk->gmn", a, b)
-    np.testing.assert_array_equal(C, ref)
-    w = rng.integers(-3, 4, (G, K, N)).astype(np.float32)               # dX = dY . W with W [K = out, N = in]
-    C = _wide(a, w, None, dgrad_view=True)
-    np.testing.assert_array_equal(C[:, :, :N], np.einsum("gmk,gkn->gmn", a, w))
