@@ -43,6 +43,7 @@ _SIGS = {
     "aread_l2_partials": (C.c_int, []),
     "aread_l2_table": (C.c_int, [f32p, C.c_int64, C.c_float, C.c_float, f32p, f32p, vp]),
     "aread_l2_table_throttled": (C.c_int, [f32p, C.c_int64, C.c_float, C.c_float, f32p, f32p, C.c_int, vp]),
+    "aread_l2_table_dev": (C.c_int, [f32p, C.c_int64, C.c_float, f32p, f32p, vp]),
     "aread_l2_finish": (C.c_int, [f32p, C.c_int, C.c_float, f32p, C.c_int, vp]),
     "aread_gemm_bf16x3": (C.c_int, [f32p, C.c_int64, C.c_int64, f32p, C.c_int64, C.c_int64, f32p, C.c_int64, C.c_int64, f32p,
                                     C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

@@ -116,11 +116,14 @@ class _AreadFn(torch.autograd.Function):
     def backward(ctx, dprobs):
         model, st = ctx.model, ctx.st
         dprobs = dprobs.contiguous()
-        grads = torch.empty_like(model.dense)
-        de = torch.empty_like(st.e)
+        # the flat dense gradient goes straight into the model's gradient arena when no .grad is held yet (the usual
+        # zero_grad -> backward -> step loop); every parameter's .grad is a cached view of that arena
+        fresh = model._grads_fresh()
+        grads = model._grad_arena(st.e.device) if fresh else torch.empty_like(model.dense)
+        de = model._de_arena(st.e)
         L.check(L.lib().aread_backward(model._handle, C.byref(st.call), L.ptr(st.e), L.ptr(dprobs), L.ptr(grads),
                                        L.ptr(de), L.stream()))
-        model._accumulate_dense(grads, ctx.present, take=True)
+        model._accumulate_dense(grads, ctx.present, take=True, in_arena=fresh)
         gtab = torch.zeros(ctx.table_shape, dtype=torch.float32, device=de.device)
         model.embedding.scatter_grad(st.x, de, gtab, st.plan.sample_row)
         return gtab, None, None, None, None, None
@@ -146,10 +149,10 @@ class _RegFn(torch.autograd.Function):
     def backward(ctx, gout):
         (table,) = ctx.saved_tensors
         model = ctx.model
-        g = float(gout.reshape(-1)[0])      # scalar scale of the regulariser in the caller's loss
+        g = gout.reshape(-1)[:1].contiguous()      # scalar scale of the regulariser in the caller's loss: stays on the device
         gtab = torch.empty_like(table)
-        L.check(L.lib().aread_l2_table(L.ptr(table), table.numel(), model.l2_reg_embedding, g, L.ptr(gtab), None, L.stream()))
-        model._accumulate_dense(2.0 * g * model._l2_coef(table.device) * model.dense, model._reg_present, take=True)
+        L.check(L.lib().aread_l2_table_dev(L.ptr(table), table.numel(), model.l2_reg_embedding, L.ptr(g), L.ptr(gtab), L.stream()))
+        model._accumulate_dense(model._l2_coef2(table.device) * model.dense * g, model._reg_present, take=True)
         return gtab, None, None
 
 
@@ -268,7 +271,9 @@ class AREAD(HempMixin, nn.Module):
         self.register_buffer("dense", torch.zeros(lib.aread_model_param_floats(h)))
         self._ptensors = [t for t in self._tensors if t[1] == 0]
         self.dense_params = nn.ParameterList([nn.Parameter(self._view_of(self.dense, t)) for t in self._ptensors])
-        self._gflat = None
+        self.__dict__["_dparams"] = list(self.dense_params)      # plain list: iterating an nn.ParameterList costs ~2 us per item
+        self._gflat, self._garena, self._gviews, self._dearena, self._ext_views = None, None, None, None, None
+        self._mask_cache, self._presence_wo = {}, None
         self._reg_present = [t[4] > 0 for t in self._ptensors]
         self.register_buffer("bn_stats", torch.zeros(lib.aread_model_stat_floats(h)))
         self.register_buffer("bn_nbt", torch.zeros(lib.aread_model_n_bn(h), dtype=torch.int64))
@@ -332,29 +337,73 @@ class AREAD(HempMixin, nn.Module):
         for p, t in zip(self.dense_params, self._ptensors):
             p.data = self._view_of(self.dense, t)
             p.grad = None
-        self._gflat = None
+        self._gflat, self._garena, self._gviews, self._dearena, self._ext_views = None, None, None, None, None
+        self._mask_cache = {}
         return self
 
     def named_dense_parameters(self):
         """(reference state_dict key, nn.Parameter) for every dense tensor."""
         return [(t[0], p) for t, p in zip(self._ptensors, self.dense_params)]
 
-    def _accumulate_dense(self, flat, present, take=False):
+    def zero_grad(self, set_to_none: bool = True):
+        """nn.Module.zero_grad over cached parameter lists (the generic walk over 300 parameters costs 0.4 ms per step)"""
+        if "_all_params" not in self.__dict__:
+            self.__dict__["_all_params"] = list(self.parameters())
+        for p in self._all_params:
+            if p.grad is not None:
+                if set_to_none:
+                    p.grad = None
+                else:
+                    p.grad.detach_().zero_()
+
+    def _grads_fresh(self):
+        """no dense parameter holds a gradient (zero_grad(set_to_none=True) or a new model)"""
+        for p in self._dparams:
+            if p.grad is not None:
+                return False
+        return True
+
+    def _grad_arena(self, device):
+        """one flat gradient buffer per model, reused by every backward; `_gviews[i]` is parameter i's view of it"""
+        if self._garena is None or self._garena.device != torch.device(device):
+            self._garena = torch.zeros_like(self.dense)
+            self._gviews = [self._view_of(self._garena, t) for t in self._ptensors]
+        return self._garena
+
+    def _de_arena(self, e):
+        if self._dearena is None or self._dearena.shape != e.shape or self._dearena.device != e.device:
+            self._dearena = torch.empty_like(e)
+        return self._dearena
+
+    def _accumulate_dense(self, flat, present, take=False, in_arena=False):
         """Add a flat gradient contribution.  Tensors marked present get `.grad` (a view of the flat gradient buffer);
-        the others keep grad=None exactly as the reference's autograd leaves them (Adam then skips them)."""
-        fresh = all(p.grad is None for p in self.dense_params)
-        if fresh:
-            if take:
-                self._gflat = flat
-            else:
-                if self._gflat is None or self._gflat.device != flat.device:
-                    self._gflat = torch.empty_like(flat)
-                self._gflat.copy_(flat)
+        the others keep grad=None exactly as the reference's autograd leaves them (Adam then skips them).
+        in_arena: `flat` IS the model's gradient arena and no gradient was held before (the caller checked)."""
+        if in_arena:
+            self._gflat, views = flat, self._gviews
+            for p, v, pres in zip(self._dparams, views, present):
+                if pres:
+                    p.grad = v
+            return
+        fresh = self._grads_fresh()
+        if fresh and take:                      # adopt the caller's buffer (train_step's persistent bufs['gdense'], a fresh temporary)
+            self._gflat = flat
+        elif fresh:
+            arena = self._grad_arena(flat.device)
+            arena.copy_(flat)
+            self._gflat = arena
         else:
             self._gflat.add_(flat)
-        for p, t, pres in zip(self.dense_params, self._ptensors, present):
+        if self._gflat is self._garena:
+            views = self._gviews
+        else:                                   # views of an adopted buffer, cached by its address (one entry: the step buffers persist)
+            key = (self._gflat.data_ptr(), self._gflat.numel())
+            if self._ext_views is None or self._ext_views[0] != key:
+                self._ext_views = (key, [self._view_of(self._gflat, t) for t in self._ptensors])
+            views = self._ext_views[1]
+        for p, v, pres in zip(self._dparams, views, present):
             if pres and p.grad is None:
-                p.grad = self._view_of(self._gflat, t)
+                p.grad = v
 
     def _presence(self, mode_id, masks):
         """Which dense tensors are on a gradient path of a forward call (what the reference's autograd would reach)."""
@@ -458,6 +507,12 @@ class AREAD(HempMixin, nn.Module):
             self._coef[key] = host.to(device)
         return self._coef[key]
 
+    def _l2_coef2(self, device):
+        key = "2:" + str(device)
+        if key not in self._coef:
+            self._coef[key] = 2.0 * self._l2_coef(device)
+        return self._coef[key]
+
     def _l2_partials(self, device):
         key = str(device)
         if key not in self._part:
@@ -525,6 +580,29 @@ class AREAD(HempMixin, nn.Module):
         call.async_tail = 2 if async_fwd else 0          # fused step: loss / running stats finish on the library's side stream
         return call, ws, probs, gate, (masks_dev, gate, y, seg_weight, loss_out)
 
+    def _mask_info(self, d, mask, device):
+        """Host-side facts about one domain's mask, cached: packed device copy, active heads, gradient-presence list.
+        The reference decides these with host-side `if`s on device booleans in EVERY forward (aread.py:272,309,320: 33 device
+        reads per call); here one device read per (mask object, in-place version).  Key: the mask list's identity and every
+        tensor's autograd version counter (bumped by any in-place write), or the bytes of a numpy mask."""
+        key = (d, id(mask)) + tuple((id(t), t._version) if isinstance(t, torch.Tensor) else hash(np.asarray(t).tobytes()) for t in mask)
+        ent = self._mask_cache.get(key)
+        if ent is None or ent["mask"] is not mask:
+            host = [np.asarray(t.cpu() if isinstance(t, torch.Tensor) else t).astype(bool) for t in mask]
+            if not host[0].reshape(-1).any():
+                raise ValueError("mask[0] has no active level-0 tower")
+            active = np.nonzero(host[self.n_level - 1].any(axis=0))[0]
+            if active.size == 0:
+                raise RuntimeError("mask has no active last-level tower (aread.py:312-322)")
+            masks = [None] * self.n_domain
+            masks[d] = host
+            if len(self._mask_cache) > 512:
+                self._mask_cache.clear()
+            ent = {"mask": mask, "dev": self._masks_dev(masks, device), "present": self._presence(0, [host]),
+                   "active": torch.from_numpy(active).to(device)}
+            self._mask_cache[key] = ent
+        return ent
+
     def _record_gates(self, gate_row, d, memory_gate_value, tmp_memory_gate_value):
         """Side outputs of aread.py:187-200,275-295 from the kernel's [gate_rows] vector."""
         off = 0
@@ -548,7 +626,9 @@ class AREAD(HempMixin, nn.Module):
         table = self.embedding.embedding_dict.weight
         if mode == "wo_mask":
             st, gate = self._run(x, 1, 1, domain_i, None, want_gates and domain_i is not None)
-            probs = (_AreadFn.apply(table, self.dense_params[0], self, x, st, self._presence(1, None))
+            if self._presence_wo is None:
+                self._presence_wo = self._presence(1, None)
+            probs = (_AreadFn.apply(table, self.dense_params[0], self, x, st, self._presence_wo)
                      if torch.is_grad_enabled() else st.probs)
             if want_gates and domain_i is not None:
                 self._record_gates(gate[0], domain_i, memory_gate_value, False)
@@ -557,22 +637,14 @@ class AREAD(HempMixin, nn.Module):
             mask = self.domain_mask[domain_i] if current_mask is None else current_mask
             if mask is None:
                 raise ValueError("no mask for this domain (domain_mask is filled by the first regroup)")
-            act0 = np.asarray(mask[0].cpu() if isinstance(mask[0], torch.Tensor) else mask[0]).reshape(-1)
-            if not act0.any():
-                raise ValueError("mask[0] has no active level-0 tower")
             d = 0 if domain_i is None else int(domain_i)
-            masks = [None] * self.n_domain
-            masks[d] = mask
-            last = np.asarray(mask[self.n_level - 1].cpu() if isinstance(mask[0], torch.Tensor) else mask[self.n_level - 1])
-            active = np.nonzero(last.any(axis=0))[0]
-            if active.size == 0:
-                raise RuntimeError("mask has no active last-level tower (aread.py:312-322)")
-            st, gate = self._run(x, 0, 1, d, self._masks_dev(masks, x.device), want_gates)
-            probs = (_AreadFn.apply(table, self.dense_params[0], self, x, st, self._presence(0, [mask]))
+            info = self._mask_info(d, mask, x.device)
+            st, gate = self._run(x, 0, 1, d, info["dev"], want_gates)
+            probs = (_AreadFn.apply(table, self.dense_params[0], self, x, st, info["present"])
                      if torch.is_grad_enabled() else st.probs)
             if want_gates:
                 self._record_gates(gate[0], d, memory_gate_value, tmp_memory_gate_value)
-            y_stack = probs[torch.from_numpy(active).to(x.device)]
+            y_stack = probs[info["active"]]
             return y_stack if mode == "domain_mask_bagging" else y_stack.mean(dim=0)
         if mode == "with_mask":
             if any(m is None for m in self.domain_mask):
@@ -837,7 +909,7 @@ class AREAD(HempMixin, nn.Module):
             torch.add(bufs["loss"][:1], bufs["reg"][:1], out=bufs["total"])
         self._mark("join parameter gradients + dense L2 + total")
         if set_grads:
-            for p in self.dense_params:
+            for p in self._dparams:
                 p.grad = None
             present = [a or b for a, b in zip(self._presence(0, self.domain_mask), self._reg_present)] if with_reg \
                 else self._presence(0, self.domain_mask)

@@ -12,8 +12,12 @@ typedef float l2_f4 __attribute__((ext_vector_type(4)));
 // The pass is cut into L2_BLOCKS "virtual blocks" (one partial sum each, a grid-stride sweep each); a launch of fewer
 // real workgroups lets every workgroup walk several virtual blocks.  Result and partial sums are therefore bitwise
 // independent of the launch width, which is the throttle of aread_l2_table_throttled.
-__global__ __launch_bounds__(L2_THREADS) void k_l2_table(const float* __restrict__ w, int64_t n, float gscale,
-                                                         float* __restrict__ grad, float* __restrict__ partial) {
+__global__ __launch_bounds__(L2_THREADS) void k_l2_table(const float* __restrict__ w, int64_t n, float gscale_host,
+                                                         float* __restrict__ grad, float* __restrict__ partial,
+                                                         const float* __restrict__ gscale_dev) {
+    // gscale_dev (nullable): a device scalar factor of the gradient -- autograd's dL/dreg arrives as a device tensor and
+    // reading it on the host would stall the stream (aread_l2_table_dev)
+    const float gscale = gscale_dev ? gscale_host * gscale_dev[0] : gscale_host;
     const int64_t n4 = n >> 2;
     const float4* w4 = (const float4*)w;
     float4* g4 = (float4*)grad;
@@ -84,7 +88,16 @@ extern "C" int aread_l2_table_throttled(const float* w, int64_t n, float l2, flo
     int blocks = L2_BLOCKS;
     if (max_workgroups > 0 && max_workgroups < blocks) blocks = max_workgroups;
     hipLaunchKernelGGL(k_l2_table, dim3(blocks), dim3(L2_THREADS), 0, (hipStream_t)stream, w, n,
-                       2.0f * l2 * grad_scale, grad, partial);
+                       2.0f * l2 * grad_scale, grad, partial, (const float*)nullptr);
+    AR_LAUNCH_CHECK();
+    return AREAD_OK;
+}
+
+extern "C" int aread_l2_table_dev(const float* w, int64_t n, float l2, const float* grad_scale_dev, float* grad, void* stream) {
+    AR_CHECK_ARG(w != nullptr && n > 0 && grad && grad_scale_dev, "aread_l2_table_dev: null pointer / empty input");
+    AR_CHECK_ARG(((uintptr_t)w & 15) == 0 && ((uintptr_t)grad & 15) == 0, "aread_l2_table_dev: 16-byte alignment");
+    hipLaunchKernelGGL(k_l2_table, dim3(L2_BLOCKS), dim3(L2_THREADS), 0, (hipStream_t)stream, w, n, 2.0f * l2, grad,
+                       (float*)nullptr, grad_scale_dev);
     AR_LAUNCH_CHECK();
     return AREAD_OK;
 }

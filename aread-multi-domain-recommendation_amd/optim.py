@@ -228,13 +228,13 @@ class Adam(torch.optim.Optimizer):
             cfg = self._cfg(self._t_table)
             L.check(lib.aread_adam_step(L.ptr(table.data), L.ptr(g), L.ptr(self._m_table), L.ptr(self._v_table), table.numel(),
                                         None, C.byref(cfg), L.stream()))
-        present = np.array([p.grad is not None for p in m.dense_params], dtype=bool)
+        present = np.array([p.grad is not None for p in m._dparams], dtype=bool)
         if present.any():
             if self._m_dense is None:
                 self._m_dense, self._v_dense = torch.zeros_like(m.dense), torch.zeros_like(m.dense)
             gflat = m._gflat                                   # every present .grad is a view of this flat buffer
             k = int(np.argmax(present))
-            if gflat is None or m.dense_params[k].grad.data_ptr() != gflat.data_ptr() + 4 * m._ptensors[k][2]:
+            if gflat is None or m._dparams[k].grad.data_ptr() != gflat.data_ptr() + 4 * m._ptensors[k][2]:
                 raise RuntimeError("aread_amd.Adam: dense gradients must come from this module's backward (views of one buffer)")
             self._t_dense[present] += 1
             for t in np.unique(self._t_dense[present]):

@@ -140,6 +140,9 @@ int aread_l2_table(const float* w, int64_t n, float l2, float grad_scale, float*
  * gradient and partial sums as aread_l2_table at any width. */
 int aread_l2_table_throttled(const float* w, int64_t n, float l2, float grad_scale, float* grad,
                              float* partial, int max_workgroups, void* stream);
+/* Gradient only, scaled by a DEVICE scalar: grad[i] = 2*l2*grad_scale_dev[0]*w[i].  The backward of get_regularization_loss
+ * under autograd (layer.py:96-112): dL/dreg arrives as a device tensor, reading it on the host would stall the stream. */
+int aread_l2_table_dev(const float* w, int64_t n, float l2, const float* grad_scale_dev, float* grad, void* stream);
 int aread_l2_finish(const float* partial, int n_partial, float l2, float* loss_out, int accumulate,
                     void* stream);
 
