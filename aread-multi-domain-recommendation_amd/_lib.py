@@ -52,6 +52,7 @@ _SIGS = {
     "aread_debug_set": (C.c_int, [C.c_char_p, C.c_int]),
     "aread_debug_get": (C.c_longlong, [C.c_char_p]),
     "aread_debug_phase_times": (C.c_int, [C.c_void_p, C.c_int]),
+    "aread_debug_gather_roof": (C.c_int, [i32p, C.c_int64, f32p, C.c_int, f32p, C.c_int64, vp]),
     "aread_gemm": (C.c_int, [f32p, C.c_int64, C.c_int64, C.c_int, f32p, C.c_int64, C.c_int64, C.c_int, f32p, C.c_int64,
                              C.c_int64, f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
 }

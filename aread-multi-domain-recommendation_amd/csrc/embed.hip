@@ -82,6 +82,49 @@ __global__ __launch_bounds__(EMB_THREADS) void k_embed_fwd(
     }
 }
 
+// ---- measurement only: the most favourable form of the gather's memory traffic -------------------------------------------
+// n_read random 128-byte-class rows (E floats each) read through PRE-RESOLVED row indices and n_write rows written as a stream:
+// no id -> row dependency beyond one index load per row, no field / pooling logic, every load of a thread in flight before the
+// first use (RD rows per thread), 16 bytes per lane.  What k_embed_fwd could reach if its id decoding, history pooling and
+// plan lookup were free: bench.py quotes the gather against this beside the 8 TB/s figure (gather_roofline.achievable_us).
+template <int RD>
+__global__ __launch_bounds__(256) void k_gather_roof(const int32_t* __restrict__ rows, int64_t n_read, const v4f* __restrict__ table,
+                                                     v4f* __restrict__ out, int64_t n_write, int e4) {
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t item = tid / e4;
+    const int c4 = (int)(tid - item * e4);
+    const int64_t r0 = item * RD;
+    if (r0 >= n_read) return;
+    int32_t idx[RD];
+#pragma unroll
+    for (int j = 0; j < RD; ++j) idx[j] = r0 + j < n_read ? rows[r0 + j] : rows[r0];
+    v4f v[RD];
+#pragma unroll
+    for (int j = 0; j < RD; ++j) v[j] = table[(int64_t)idx[j] * e4 + c4];
+    // the same rows-in : rows-out ratio as the real gather (n_write / n_read): sums of consecutive reads become one output row
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < RD; ++j) {
+        acc += v[j];
+        const int64_t r = r0 + j;
+        if (r < n_read && ((r + 1) * n_write / n_read) != (r * n_write / n_read)) {
+            out[(r * n_write / n_read) * e4 + c4] = acc;
+            acc = (v4f){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+}
+extern "C" int aread_debug_gather_roof(const int32_t* rows, int64_t n_read, const float* table, int E, float* out, int64_t n_write,
+                                       void* stream) {
+    AR_CHECK_ARG(rows && table && out && n_read > 0 && n_write > 0 && n_write <= n_read && E > 0 && E % 4 == 0, "aread_debug_gather_roof: bad arguments");
+    constexpr int RD = 8;
+    const int e4 = E / 4;
+    const int64_t threads = (n_read + RD - 1) / RD * e4;
+    hipLaunchKernelGGL(k_gather_roof<RD>, dim3(cdiv(threads, 256)), dim3(256), 0, (hipStream_t)stream, rows, n_read, (const v4f*)table,
+                       (v4f*)out, n_write, e4);
+    AR_LAUNCH_CHECK();
+    return AREAD_OK;
+}
+
 extern "C" int aread_embed_fwd(const int32_t* x, int64_t B, int f_in, const int32_t* offsets, const float* table,
                                int64_t n_table_rows, int E, int n_onehot, int n_mh_fields, int seq_len, int pool,
                                const int32_t* row_sample, int64_t n_rows_out, float* out, int32_t* bag_out,

@@ -319,6 +319,10 @@ long long aread_debug_get(const char* key);
 /* Diagnostics: after aread_debug_set("phase_events", 1) the forward / backward record events at their phase boundaries on
  * the caller's stream; this returns the elapsed GPU time (ms) between consecutive boundaries of the last call. */
 int aread_debug_phase_times(float* out_ms, int n);
+/* Measurement only (bench.py gather_roofline.achievable_us, tools/mem_roof.py): n_read table rows of E floats read through
+ * pre-resolved row indices (eight in flight per lane, 16 bytes per lane) and n_write <= n_read output rows streamed out (sums
+ * of consecutive reads) -- the gather's memory traffic without its id decoding, pooling and plan lookups. */
+int aread_debug_gather_roof(const int32_t* rows, int64_t n_read, const float* table, int E, float* out, int64_t n_write, void* stream);
 /* Makes `stream` wait for the model's internal side stream (see aread_call.async_tail). */
 int aread_join(const aread_model* m, void* stream);
 /* Dense L2 terms: loss_out[0] (+)= sum_i coef[i]*w[i]^2, grads[i] += 2*coef[i]*w[i] (grads may be NULL).
