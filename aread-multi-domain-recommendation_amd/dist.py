@@ -209,8 +209,23 @@ def all_reduce_any(t, group=None):
 
 
 class Route:
-    """Result of ShardRouter.route for one batch."""
-    __slots__ = ("slot", "n_unique", "send", "recv", "recv_rows")
+    """Result of ShardRouter.route for one batch.  overflow: device bool (fixed-capacity exchange only) -- a peer's share of
+    the unique rows exceeded the capacity, the step's results are invalid (ShardedTableStep checks it one step later)."""
+    __slots__ = ("slot", "n_unique", "send", "recv", "recv_rows", "overflow")
+
+
+def all_to_all_equal(inp, group=None):
+    """Equal-split all-to-all along dim 0 (inp.shape[0] % world == 0): no split sizes, nothing read on the host."""
+    if _alone(group):
+        return inp.clone()
+    out = torch.empty_like(inp)
+    if _backend(group) == "gloo" and inp.is_cuda:
+        o = torch.empty(inp.shape, dtype=inp.dtype)
+        dist.all_to_all_single(o, inp.cpu().contiguous(), group=group)
+        out.copy_(o)
+        return out
+    dist.all_to_all_single(out, inp.contiguous(), group=group)
+    return out
 
 
 class ShardRouter:
@@ -278,25 +293,81 @@ class ShardRouter:
         send_cnt = (edges[1:] - edges[:-1]).to(torch.int64)
         both = torch.stack([send_cnt, all_to_all_rows(send_cnt, [1] * P, [1] * P, self.group)]).tolist()   # host read
         r = Route()
+        r.overflow = None
         r.send, r.recv = [int(v) for v in both[0]], [int(v) for v in both[1]]
         r.n_unique = sum(r.send)
         r.slot = slot                                                # lookup -> slot in this rank's unique-row buffer
         r.recv_rows = all_to_all_rows(uniq_rows[:r.n_unique], r.recv, r.send, self.group)        # local rows asked of me
         return r
 
-    def route(self, bag):
+    def _exchange_fixed(self, slot, uniq_rows, edges, cap):
+        """Fixed-capacity exchange: every rank asks every peer for exactly `cap` rows -- its unique rows of that owner, padded
+        with the owner's local row 0 -- so the split sizes are constants: NO host read, the whole sharded step can be queued
+        (and captured) without waiting for the routing kernels.  The unique-row buffer then has P*cap slots (owner-major,
+        `cap` per owner); padded slots are never referenced by a lookup, fetch whatever row 0 holds and push zero gradients.
+        A peer share above the capacity sets route.overflow (device flag): the caller checks it off the critical path."""
+        P = self.P
+        dev = uniq_rows.device
+        e = edges.to(torch.int64)                                           # [P+1] owner boundaries of the compact unique list
+        n = uniq_rows.numel()
+        ar = torch.arange(n, device=dev, dtype=torch.int64)
+        owner = torch.bucketize(ar, e[1:].contiguous(), right=True).clamp_(max=P - 1)      # owner of compact entry i (garbage past n_unique)
+        pos = ar - e[owner]
+        ok = (ar < e[P]) & (pos < cap)
+        dst = torch.where(ok, owner * cap + pos, torch.full_like(ar, P * cap))               # dropped entries go to a dummy slot
+        req = torch.zeros(P * cap + 1, dtype=uniq_rows.dtype, device=dev)
+        req.scatter_(0, dst, uniq_rows)
+        s64 = slot.reshape(-1).to(torch.int64)
+        so = torch.bucketize(s64, e[1:].contiguous(), right=True).clamp_(max=P - 1)
+        r = Route()
+        r.slot = (s64 - e[so] + so * cap).clamp_(max=P * cap - 1).to(torch.int32).reshape(slot.shape)
+        r.overflow = ((e[1:] - e[:-1]) > cap).any()
+        r.send, r.recv = [cap] * P, [cap] * P
+        r.n_unique = P * cap
+        r.recv_rows = all_to_all_equal(req[:P * cap].contiguous(), self.group)             # local rows asked of me, cap per peer
+        return r
+
+    def route(self, bag, capacity=None):
+        if capacity is not None:
+            return self._exchange_fixed(*self.dedupe(bag), int(capacity))
         return self._exchange(*self.dedupe(bag))
 
-    def route_hip(self, x, offsets):
+    def route_hip(self, x, offsets, capacity=None):
+        if capacity is not None:
+            return self._exchange_fixed(*self.dedupe_hip(x, offsets), int(capacity))
         return self._exchange(*self.dedupe_hip(x, offsets))
+
+    def peer_counts(self, edges):
+        """unique rows this rank asks of each owner (device tensor [P]); capacity calibration reads its maximum once"""
+        return (edges[1:] - edges[:-1]).to(torch.int64)
 
     def fetch(self, route, rows):
         """rows [sum(recv), E] (this rank's rows for route.recv_rows) -> [n_unique, E] in slot order"""
+        if getattr(route, "overflow", None) is not None:
+            return all_to_all_equal(rows, self.group)
         return all_to_all_rows(rows, route.send, route.recv, self.group)
 
     def push(self, route, g_unique):
         """g_unique [n_unique, E] -> [sum(recv), E] aligned with route.recv_rows"""
+        if getattr(route, "overflow", None) is not None:
+            return all_to_all_equal(g_unique, self.group)
         return all_to_all_rows(g_unique, route.recv, route.send, self.group)
+
+
+def zero_bounds(tensors, n, P):
+    """ZeRO-1 chunk boundaries of the flat dense parameter cut ON TENSOR BOUNDARIES: b[0] = 0 <= b[1] <= ... <= b[P] = n with
+    every b[q] the start offset of a tensor (the start nearest to q*n/P), so that a whole expert / tower / gate tensor -- weights,
+    its Adam moments, its step count -- lives on one rank (north star: "domain-expert towers partition across the GPUs").
+    tensors: (name, kind, offset, shape, l2) of the model's trainable tensors."""
+    import numpy as np
+    starts = np.array(sorted({int(t[2]) for t in tensors} | {0}), dtype=np.int64)
+    b = [0]
+    for q in range(1, P):
+        target = q * n / P
+        cand = int(starts[np.argmin(np.abs(starts - target))])
+        b.append(max(cand, b[-1]))
+    b.append(int(n))
+    return b
 
 
 class ShardedTableStep:
@@ -314,12 +385,17 @@ class ShardedTableStep:
     The loss convention is the DataParallelStep's: objective = sum over ranks of the rank losses + reg (once).
     Two host reads per step (unique count, split sizes) -- the usual price of a variable-size all-to-all."""
 
-    def __init__(self, model, B, group=None):
+    def __init__(self, model, B, group=None, capacity=None):
+        """capacity: rows per peer of the FIXED-capacity all-to-all (ShardRouter._exchange_fixed): no host read anywhere in the
+        step (capturable); None = variable-size exchange with one host read of 2P counts (prefetched one batch ahead).
+        calibrate_capacity(x) measures a value on a sample batch."""
         import ctypes as C
         from . import _lib as L
         self._C, self._L = C, L
         self.model, self.group = model, group
         self.P, self.p = _world(group), _rank(group)
+        self.capacity = None if capacity is None else int(capacity)
+        self._ovf_prev = None
         emb = model.embedding
         table = emb.embedding_dict.weight.data
         dev = table.device
@@ -328,13 +404,15 @@ class ShardedTableStep:
         self.gshard = torch.empty_like(self.shard.data)
         self.bufs = model.make_step_buffers(B, multi_domain=True, with_table_grad=False)
         n = model.dense.numel()
-        self.chunk = (n + self.P - 1) // self.P
+        # ZeRO-1 chunks cut on tensor boundaries (zero_bounds); the collectives want equal sizes, so every rank's chunk is
+        # padded to the longest one: packed layout [P][chunk], rank q's tensors at q*chunk .. q*chunk + (b[q+1] - b[q])
+        self.bounds = zero_bounds(model._ptensors, n, self.P)
+        self.chunk = (max(self.bounds[q + 1] - self.bounds[q] for q in range(self.P)) + 3) // 4 * 4
         self.gpad = torch.zeros(self.chunk * self.P, dtype=torch.float32, device=dev)
-        self.bufs["gdense"] = self.gpad[:n]                           # the backward writes straight into the padded buffer
         self.dense_pad = torch.zeros(self.chunk * self.P, dtype=torch.float32, device=dev)
-        self.dense_pad[:n].copy_(model.dense.data)
         self.coef_pad = torch.zeros(self.chunk * self.P, dtype=torch.float32, device=dev)
-        self.coef_pad[:n].copy_(model._l2_coef(dev))
+        self._pack(self.dense_pad, model.dense.data)
+        self._pack(self.coef_pad, model._l2_coef(dev))
         lo = self.p * self.chunk
         self.dense_chunk = torch.nn.Parameter(self.dense_pad[lo:lo + self.chunk].clone())
         self.gchunk = torch.zeros(self.chunk, dtype=torch.float32, device=dev)
@@ -346,6 +424,35 @@ class ShardedTableStep:
         self._pref, self._route_stream = None, None
         self._opt = None
         self._side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+
+    def _pack(self, padded, flat):
+        """flat [n] (the library's tensor order) -> packed [P][chunk]"""
+        for q in range(self.P):
+            lo, hi = self.bounds[q], self.bounds[q + 1]
+            if hi > lo:
+                padded[q * self.chunk:q * self.chunk + hi - lo].copy_(flat[lo:hi])
+        return padded
+
+    def _unpack(self, flat, padded):
+        for q in range(self.P):
+            lo, hi = self.bounds[q], self.bounds[q + 1]
+            if hi > lo:
+                flat[lo:hi].copy_(padded[q * self.chunk:q * self.chunk + hi - lo])
+        return flat
+
+    def calibrate_capacity(self, x, margin=1.25):
+        """rows per peer for the fixed-capacity exchange from a sample batch: the largest per-owner unique count over all
+        ranks x margin, rounded up to 64 (ONE host read, outside the training loop); sets and returns self.capacity"""
+        emb = self.model.embedding
+        _, _, edges = self.router.dedupe_hip(x, emb._offsets_dev(x.device))
+        mx = self.router.peer_counts(edges).max().reshape(1).to(torch.float32)
+        if not _alone(self.group):
+            if _backend(self.group) == "gloo" and mx.is_cuda:
+                c = mx.cpu(); dist.all_reduce(c, op=dist.ReduceOp.MAX, group=self.group); mx = c
+            else:
+                dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.group)
+        self.capacity = (int(float(mx) * margin) + 63) // 64 * 64
+        return self.capacity
 
     # ---- C-ABI helpers -------------------------------------------------------------------------------------------
     def _bwd_ws(self, tag, B, f_in):
@@ -382,7 +489,7 @@ class ShardedTableStep:
         rs = self._route_stream
         rs.wait_stream(torch.cuda.current_stream())                  # (x_next may have been produced on the main stream)
         with torch.cuda.stream(rs):
-            route = self.router.route_hip(x_next, emb._offsets_dev(x_next.device))      # host read: waits for rs only
+            route = self.router.route_hip(x_next, emb._offsets_dev(x_next.device), self.capacity)   # (variable-size: host read, waits for rs only)
             ev = torch.cuda.Event()
             ev.record(rs)
         self._pref = ((x_next.data_ptr(), tuple(x_next.shape)), route, ev)
@@ -398,7 +505,13 @@ class ShardedTableStep:
             for t in (route.slot, route.recv_rows):
                 t.record_stream(torch.cuda.current_stream())
         else:
-            route = self.router.route_hip(x, emb._offsets_dev(x.device))
+            route = self.router.route_hip(x, emb._offsets_dev(x.device), self.capacity)
+        if route.overflow is not None:
+            # fixed capacity: the flag of THIS batch is looked at when the next step is issued (by then it was computed long ago)
+            if self._ovf_prev is not None and bool(self._ovf_prev):
+                raise RuntimeError(f"ShardedTableStep: a peer's share of the previous batch's unique rows exceeded capacity={self.capacity}: "
+                                   "that step's lookup was incomplete -- raise the capacity (calibrate_capacity) and redo it")
+            self._ovf_prev = route.overflow
         urows = self.router.fetch(route, self._gather_owned(route.recv_rows))
         L.check(L.lib().aread_embed_fwd(L.ptr(route.slot), x.shape[0], x.shape[1], L.ptr(self._zero17), L.ptr(urows),
                                         urows.shape[0], emb.embed_dim, emb.one_hot_field_num, emb.multi_hot_field_num,
@@ -462,7 +575,8 @@ class ShardedTableStep:
         side.wait_stream(main)
         with torch.cuda.stream(side):
             m.step_finish(b)                                           # dense gradients of the local batch complete
-            reduce_scatter_flat(self.gchunk, self.gpad, self.group)    # bufs['gdense'] is a view of gpad
+            self._pack(self.gpad, b["gdense"])                         # tensor-aligned chunks, padded to equal length
+            reduce_scatter_flat(self.gchunk, self.gpad, self.group)
             self.reg.copy_(b["reg"])                                   # table L2 of this shard
             L.check(lib.aread_l2_dense(L.ptr(self.dense_chunk.data), L.ptr(self.coef_pad[lo:lo + self.chunk]), self.chunk,
                                        L.ptr(self.gchunk), L.ptr(self.reg), 1, L.stream()))
@@ -511,16 +625,18 @@ class ShardedTableStep:
             sel = present & (o["t_dense"] == t)
             k = sel.tobytes()
             if k not in o["act"]:                                   # uint8 [chunk]: 1 on this rank's elements of the selected tensors
-                a = np.zeros(self.chunk * self.P, dtype=np.uint8)
+                a = np.zeros(m.dense.numel(), dtype=np.uint8)
                 for on, (name, kind, off, shape, l2) in zip(sel, m._ptensors):
                     if on:
                         a[off:off + (int(np.prod(shape)) if shape else 1)] = 1
-                o["act"][k] = torch.from_numpy(a[lo:lo + self.chunk].copy()).to(self.gchunk.device)
+                mine = np.zeros(self.chunk, dtype=np.uint8)              # this rank's tensors (zero_bounds), padded
+                mine[:self.bounds[self.p + 1] - self.bounds[self.p]] = a[self.bounds[self.p]:self.bounds[self.p + 1]]
+                o["act"][k] = torch.from_numpy(mine).to(self.gchunk.device)
             c = cfg(t)
             L.check(lib.aread_adam_step(L.ptr(self.dense_chunk.data), L.ptr(self.gchunk), L.ptr(o["m_chunk"]), L.ptr(o["v_chunk"]),
                                         self.chunk, L.ptr(o["act"][k]), C.byref(c), L.stream()))
         all_gather_flat(self.dense_pad, self.dense_chunk.data, self.group)
-        self.model.dense.data.copy_(self.dense_pad[:self.model.dense.numel()])
+        self._unpack(self.model.dense.data, self.dense_pad)
 
     def full_table(self):
         """gathers the shards back into a [R, E] table (checkpointing / tests)"""

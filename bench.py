@@ -48,6 +48,8 @@ def parse(argv=None):
                     "critical path) instead of prefetching the next batch's routing during the current step")
     ap.add_argument("--no-prefetch", action="store_true", help="eager step: row plan and index sort inside the step (A/B of "
                     "AREAD.prepare_batch)")
+    ap.add_argument("--variable-exchange", action="store_true", help="sharded table: variable-size all-to-all (one host read of 2P "
+                    "counts per batch, prefetched) instead of the fixed-capacity exchange")
     ap.add_argument("--step-only", action="store_true", help="profiling: run only the warm-up + timed steps (no roofline "
                     "micro-loops, no forward-only / fused-optimizer extras, no CPU baseline), so rocprofv3 sees the pure step")
     ap.add_argument("--kernels-only", action="store_true", help="profiling: one step to size the buffers, then only the "
@@ -237,9 +239,14 @@ def main():
         variants = {"replicated": (lambda: dp.step(xs, ys, masks_dev), bufs["total"])}
         if args.table != "replicated":
             sh = D.ShardedTableStep(model, B)
-            # the routing (dedupe + split sizes, one host read) of the NEXT batch is prefetched on its own stream while this step
-            # runs -- an input-pipeline stage like the batch copy itself; it is executed inside the timed region, once per step
-            prefetch = not args.no_route_prefetch
+            if not args.variable_exchange:
+                # fixed-capacity all-to-all: constant split sizes (the largest per-peer unique-row count of the batches x 1.25),
+                # nothing is read on the host inside the step; an overflow is reported one step later (ShardedTableStep.lookup)
+                sh.capacity = max(sh.calibrate_capacity(bt[0]) for bt in batches)
+                log(f"sharded table: fixed exchange capacity {sh.capacity} rows per peer")
+            # variable-size exchange only: the routing (dedupe + split sizes, one host read) of the NEXT batch is prefetched on its
+            # own stream while this step runs -- an input-pipeline stage like the batch copy itself, inside the timed region
+            prefetch = not args.no_route_prefetch and args.variable_exchange
             variants["sharded"] = (lambda: sh.step(xs, ys, masks_dev, next_x=batches[(cur["i"] + 1) % n_batches][0] if prefetch else None,
                                                    x_key=batches[cur["i"] % n_batches][0].data_ptr()), sh.total)
         dp_state["variant"] = "sharded" if args.table == "sharded" else "replicated"
@@ -434,7 +441,9 @@ def main():
                                                    ": replicated table, all_gather(ids,dE)+all_reduce(dense grads) over RCCL"
                                                    if dp_state["variant"] == "replicated" else
                                                    ": row-sharded table (r % P), all_to_all(ids,rows,row grads)+"
-                                                   "reduce_scatter(dense grads) over RCCL, 2 host reads/step"),
+                                                   "reduce_scatter(dense grads on tensor-aligned ZeRO chunks) over RCCL, "
+                                                   + ("variable splits: one prefetched host read per batch" if args.variable_exchange
+                                                      else "fixed-capacity exchange: no host read")),
                    **({"table_variants_ms": dp_state["times_ms"]} if "times_ms" in dp_state else {})},
         "roofline": roofline, "gemm_roofline": gemm, "wgrad_roofline": wgrad, "l2_table_roofline": l2pass, "gather_roofline": gather,
         "gather_roofline_b65536": gather_big,

@@ -130,6 +130,17 @@ def _shard_worker(rank, world, port, q):
             br, gr = _shard_data(None, r, B, n_rows, E)
             np.add.at(exp, br.reshape(-1), gr.astype(np.float64))
         ok_bwd = np.allclose(got, exp, rtol=1e-12, atol=1e-12)
+        # fixed-capacity exchange (constant split sizes, nothing read on the host): same rows, same gradients; overflow flag
+        cap = 64 * 17
+        rf = router.route(torch.from_numpy(bag), capacity=cap)
+        uf = router.fetch(rf, shard[rf.recv_rows.long()])
+        ok_fwd = ok_fwd and rf.n_unique == world * cap and not bool(rf.overflow) and \
+            torch.equal(uf[rf.slot.long()], table[torch.from_numpy(bag).long()])
+        gu = torch.zeros(rf.n_unique, E, dtype=torch.float64).index_add_(0, rf.slot.reshape(-1).long(), torch.from_numpy(g_lookup).double())
+        gr = router.push(rf, gu)
+        gshard_f = torch.zeros(shard.shape, dtype=torch.float64).index_add_(0, rf.recv_rows.long(), gr)
+        ok_bwd = ok_bwd and torch.allclose(gshard_f, gshard, rtol=1e-12, atol=1e-12)
+        ok_dedupe = ok_dedupe and bool(router.route(torch.from_numpy(bag), capacity=8).overflow)
         # shard_of / unshard round trip over every rank's shard
         tabs = [torch.empty_like(shard) for _ in range(world)]
         dist.all_gather(tabs, shard)
@@ -172,3 +183,21 @@ def test_shard_router_single_process():
     assert route.n_unique == 4 and route.send == [4] and route.recv == [4]
     assert route.recv_rows.tolist() == [0, 3, 7, 49]
     assert route.slot.tolist() == [[1, 1, 3], [0, 1, 2]]
+    rf = router.route(bag, capacity=6)
+    assert rf.n_unique == 6 and rf.recv_rows.tolist() == [0, 3, 7, 49, 0, 0] and rf.slot.tolist() == route.slot.tolist() and not bool(rf.overflow)
+    assert bool(router.route(bag, capacity=3).overflow)
+
+
+def test_zero_bounds_on_tensor_boundaries():
+    """ZeRO-1 chunks: boundaries are tensor starts, monotone, cover [0, n], near the equal split"""
+    import aread_amd.dist as D
+    rng = np.random.default_rng(1)
+    sizes = rng.integers(1, 5000, 200)
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    tensors = [("t%d" % i, 0, int(offs[i]), (int(sizes[i]),), 0.0) for i in range(len(sizes))]
+    n = int(offs[-1])
+    for P in (1, 2, 3, 8):
+        b = D.zero_bounds(tensors, n, P)
+        assert len(b) == P + 1 and b[0] == 0 and b[-1] == n and all(b[i] <= b[i + 1] for i in range(P))
+        assert all(v in set(offs.tolist()) for v in b)
+        assert max(abs(b[q] - q * n / P) for q in range(P + 1)) <= 5000
