@@ -932,6 +932,9 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     // 5a. experts, all layers but the first: main stream, issued before any side work
     for (int j = nle - 1; j >= 1; --j)
         TRY(layer_bwd(x, m->experts.L[j], x.w.ex[j], ws + x.w.ex[j - 1].Act, ws + x.w.ex[j - 1].dAct, 0, grads, -1, x.w.slab_ex[j]));
+    const int n_pend_b = x.n_pend;                           // ... and the deeper expert layers' (their dH is final here)
+    hipEvent_t ev_b2 = nullptr;
+    if (n_pend_b > n_pend_a) TRY(mark_main(&ev_b2));         // (one record: their weight gradients leave the side stream's tail)
     // ---- side stream, batch A ------------------------------------------------------------------------------------------------
     x.st = x.side;
     AR_HIP(hipStreamWaitEvent(x.side, ev_b1, 0));      // (the side stream's first wait of this call: dz, dglog*, dH of the towers are final)
@@ -939,6 +942,10 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     hipEvent_t ev_gates = x.m->ev[x.ev_next++ % (x.m->n_ev - 1)];   // side2's cue: behind ev_b1 and behind the gradient buffer's initialisation
     AR_HIP(hipEventRecord(ev_gates, x.side));
     TRY(flush_wgrads_range(x, 0, n_pend_a));             // head, tower and gate weight gradients: one launch
+    if (ev_b2) {
+        AR_HIP(hipStreamWaitEvent(x.side, ev_b2, 0));
+        TRY(flush_wgrads_range(x, n_pend_a, n_pend_b));  // expert layers n-1 .. 1: one launch, beside the first layer's act/BN backward
+    }
     x.st = main_st;
     // ---- side2: row-wise trunk backward beside the expert backward.  It needs dcn / dlin and dq / deg (all ordered behind
     // ev_gates on the side stream) and WRITES its share of dL/de: into c->de_rw when the caller gave one (the embedding
@@ -1004,6 +1011,15 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
             if (m->gate_rows > mxc) mxc = m->gate_rows;
             LAUNCH(k_reduce_tiles_all, dim3(cdiv(mxc, 32), ra.n), dim3(256), ra);
         }
+        // the forward's deferred tail (loss value, running statistics): this stream has the slack (the side stream's last
+        // reductions decide when the step's parameter gradients are complete)
+        if (tail_deferred) {
+            const hipStream_t keep_side = x.side;
+            x.side = rw_stream;
+            const int rc = forward_tail(x, tower_fused_ok(x));
+            x.side = keep_side;
+            if (rc != AREAD_OK) return rc;
+        }
         x.st = main_st;
     }
     // 5b. the first expert layer: its input gradient goes to de_out; without a separate de_rw it ADDS onto what the row-wise
@@ -1015,10 +1031,9 @@ extern "C" int aread_backward(const aread_model* m, const aread_call* c, const f
     // ---- side stream, batch B (its fork was recorded inside layer_bwd, right behind the act/BN backward and BEFORE the dgrad):
     // every expert layer's weight gradient in one launch, then the reductions of everything
     x.st = x.side;
-    TRY(flush_wgrads_range(x, n_pend_a, x.n_pend));
+    TRY(flush_wgrads_range(x, ev_b2 ? n_pend_b : n_pend_a, x.n_pend));   // the first expert layer's weight gradient
     x.n_pend = 0;
     TRY(flush_reductions(x));
-    if (tail_deferred) TRY(forward_tail(x, tower_fused_ok(x)));      // loss value + running statistics: nothing waits for them before the join
     x.st = main_st;
     // de_out (and de_rw) are complete on the main stream here; the parameter gradients complete on the two side streams
     // (side: weight / bias / BatchNorm gradients; side2: row-wise trunk, group embedding, gate biases, head tails).

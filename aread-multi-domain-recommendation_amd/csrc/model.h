@@ -1,6 +1,7 @@
 // model.h -- host-side layouts of the dense model: flat parameter / statistics buffers and the
 // per-call workspace.  Pure bookkeeping; no device memory is owned here.
 #pragma once
+#include <cstdlib>
 #include <string>
 #include <vector>
 #include "common.h"
@@ -97,7 +98,9 @@ static inline KSplit wgrad_ksplit(int64_t rows, int G, int M, int N) {
     const int64_t blocks_mn = (int64_t)G * ((M + 63) / 64) * ((N + tn - 1) / tn);
     // small weight gradients (towers, gates, heads) share ONE launch with a dozen others (k_gemm_bf3_rc_multi): ~128 workgroups
     // each fill the chip together, and 5-6x fewer slabs to write and to reduce than a chip-filling split of every one of them
-    const int64_t target = (int64_t)G * M * N <= 32768 ? 128 : 768;
+    static int small_target = -1;                // AREAD_WGRAD_TARGET: A/B of the small weight gradients' workgroup count
+    if (small_target < 0) { const char* e = getenv("AREAD_WGRAD_TARGET"); small_target = e ? atoi(e) : 128; }
+    const int64_t target = (int64_t)G * M * N <= 32768 ? small_target : 768;
     int64_t want = (target + blocks_mn - 1) / blocks_mn;
     const int64_t max_split = rows / TILE_M;
     if (want > max_split) want = max_split;
