@@ -803,7 +803,10 @@ class AREAD(HempMixin, nn.Module):
         # The table L2 pass (356 MB of HBM traffic, needed only by the embedding reduction at the very end) goes on the side
         # stream BEHIND the forward (AREAD_L2_EARLY=1: right after the row plan, as in round 1): next to the latency-bound head
         # of the step (gather, first GEMM) it cost those kernels 2-3x their isolated time.
+        used = {"side": False}                         # was anything queued on the torch side stream in this step?
+
         def l2_pass():
+            used["side"] = True
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 if not table_pass:
@@ -821,6 +824,7 @@ class AREAD(HempMixin, nn.Module):
         if presort and self.sort_early:
             # the index sort of the embedding backward needs only the row plan: issued (captured) BEFORE the forward so that a
             # graph replay schedules it beside the expert forward instead of behind everything else at the tail of the step
+            used["side"] = True
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 self.embedding.sort_lookups(x, plan.sample_row)
@@ -833,6 +837,7 @@ class AREAD(HempMixin, nn.Module):
         if not self.l2_pass_early and not in_bwd:
             l2_pass()
         if presort and not self.sort_early:
+            used["side"] = True
             side.wait_event(plan_ready)
             with torch.cuda.stream(side):
                 self.embedding.sort_lookups(x, plan.sample_row)
@@ -853,7 +858,8 @@ class AREAD(HempMixin, nn.Module):
         st.call.l2_table = None
         st.call.l2_dense_coef = None
         self._mark("backward (main stream: to the last dgrad)")
-        main.wait_stream(side)          # table L2 pass + index sort
+        if used["side"]:                # table L2 pass / index sort queued there (a wait on an idle stream still costs the
+            main.wait_stream(side)      # main stream ~5 us: with a prepared batch and the sweep inside the backward nothing is)
         self._pending_dense_l2 = bool(with_reg and with_dense_l2) and not dense_first
         self._dense_l2_done_first = dense_first
         self._last = (st, gate)
