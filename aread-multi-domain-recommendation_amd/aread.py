@@ -47,7 +47,8 @@ class Call(C.Structure):
                 ("y", C.c_void_p), ("seg_weight", C.c_void_p), ("loss_out", C.c_void_p), ("async_tail", C.c_int32),
                 ("l2_table", C.c_void_p), ("l2_n", C.c_int64), ("l2_coef", C.c_float), ("l2_workgroups", C.c_int32),
                 ("l2_grad", C.c_void_p), ("l2_partial", C.c_void_p), ("l2_reg_out", C.c_void_p), ("l2_dense_coef", C.c_void_p),
-                ("grads_init", C.c_int32), ("init_grads", C.c_void_p), ("init_reg_out", C.c_void_p), ("de_rw", C.c_void_p)]
+                ("grads_init", C.c_int32), ("init_grads", C.c_void_p), ("init_reg_out", C.c_void_p), ("de_rw", C.c_void_p),
+                ("inference", C.c_int32)]
 
 
 for _n, _r, _a in [
@@ -578,6 +579,7 @@ class AREAD(HempMixin, nn.Module):
         call.ws, call.probs, call.gate_stats = L.ptr(ws), L.ptr(probs), L.ptr(gate)
         call.y, call.seg_weight, call.loss_out = L.ptr(y), L.ptr(seg_weight), L.ptr(loss_out)
         call.async_tail = 2 if async_fwd else 0          # fused step: loss / running stats finish on the library's side stream
+        call.inference = int(not train and not torch.is_grad_enabled())   # eval under no_grad: BatchNorm + ReLU inside the expert GEMMs
         return call, ws, probs, gate, (masks_dev, gate, y, seg_weight, loss_out)
 
     def _mask_info(self, d, mask, device):

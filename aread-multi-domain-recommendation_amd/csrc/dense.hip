@@ -128,8 +128,18 @@ static int layer_fwd(Ctx& x, const LayerL& L, const LayerWs& lw, const float* in
     g.gate_axis = 1; g.tile_seg = x.r.tile_seg; g.tile_valid = x.r.tile_valid;
     g.active = (level >= 0 && g.G > 1) ? level_active(x, level) : nullptr; g.active_ld = MAX_TOWER;
     if (x.c->train) { g.stat_part = x.ws + lw.part; g.stat_ld = L.ncols; }
+    // inference (eval mode, no backward to follow): BatchNorm with the running statistics + ReLU in the GEMM's epilogue, the
+    // activation goes straight to Act -- no k_bn_act launch, no H round trip (expert layers; the fused tower kernel has its own)
+    const bool fold = !x.c->train && x.c->inference && level < 0;
+    if (fold) {
+        g.C = x.ws + lw.Act;
+        g.ep_rmean = x.c->stats + L.rmean; g.ep_rvar = x.c->stats + L.rvar;
+        g.ep_gamma = x.params + L.gamma; g.ep_beta = x.params + L.beta;
+        g.ep_seg_count = x.r.seg_count;
+    }
     if (x.m->cfg.precision == 1) TRY(launch_gemm_bf3(g, x.st));
     else TRY(launch_gemm(g, true, true, x.st));
+    if (fold) return AREAD_OK;
     BnActP a = {};
     a.H = x.ws + lw.H; a.Act = x.ws + lw.Act; a.part = x.ws + lw.part;
     a.mean = x.ws + lw.mean; a.rstd = x.ws + lw.rstd; a.var = x.ws + lw.var;

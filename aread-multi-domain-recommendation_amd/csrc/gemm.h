@@ -39,7 +39,12 @@ struct GemmP {
     int gate_axis;                           // 0 none, 1 = M, 2 = K
     // BatchNorm statistics epilogue (forward): per m-tile, per column: (mean, M2) over the valid rows
     float* stat_part; int64_t stat_ld;       // stat_part[(tile_m*stat_ld + g*N + n)*2 + {0,1}]
-    int dbg;                                 // timing-only ablation bits of k_gemm_bf3w (tools/gemm_wide_bench.py); 0 in the product
+    int dbg;                                 // (unused)
+    // inference epilogue (forward with running statistics and no backward to follow): BatchNorm + ReLU applied to the
+    // accumulators, C receives the ACTIVATION (the pre-BatchNorm H is not kept), padding rows are written as zeros.
+    // BatchNorm is skipped for one-row segments (layer.py:226).  Indexed like bias: [g*bias_gs + n].  Needs gate_axis == 1.
+    const float* ep_rmean; const float* ep_rvar; const float* ep_gamma; const float* ep_beta;
+    const int32_t* ep_seg_count;
 };
 
 // LDS image of an operand tile.  KC operands: [rows][BK+2] (k contiguous, as in global memory).
@@ -142,6 +147,26 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[NI], 
         const float bv = (p.bias && n < p.N) ? p.bias[(int64_t)g * p.bias_gs + n] : 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[i][r] += bv;
+    }
+    if (p.ep_gamma) {
+        const int seg = p.tile_seg[by];
+        const bool bn = p.ep_seg_count[seg] > 1;
+        const int nv = p.tile_valid[by];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int n = n0 + i * 16 + col_in;
+            if (n < p.N) {
+                const int64_t o = (int64_t)g * p.bias_gs + n;
+                const float mu = p.ep_rmean[o], rs = 1.0f / sqrtf(p.ep_rvar[o] + 1e-5f), ga = p.ep_gamma[o], be = p.ep_beta[o];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[i][r];
+                    if (bn) v = (v - mu) * rs * ga + be;
+                    v = v > 0.f ? v : 0.f;
+                    acc[i][r] = (row_base + r < nv) ? v : 0.f;
+                }
+            }
+        }
     }
     const bool vec_ok = (n0 + TN <= p.N) && (m0 + 64 <= p.M) && ((p.ldc & 3) == 0) && ((p.c_gs & 3) == 0) &&
                         ((p.c_ks & 3) == 0) && (((uintptr_t)p.C & 15) == 0);

@@ -266,6 +266,9 @@ typedef struct aread_call {
      * embedding backward aread_embed_bwd_reduce2 adds them on the fly) and the first expert layer's dgrad no longer waits for
      * the row-wise chain.  NULL: de_out holds the whole gradient. */
     float* de_rw;
+    /* aread_forward, train == 0 only: non-zero = no backward will follow this forward (torch.no_grad evaluation, run.py:712-763):
+     * the expert layers apply BatchNorm (running statistics) + ReLU in their GEMM epilogue and do not keep the pre-BatchNorm H. */
+    int32_t inference;
 } aread_call;
 
 /* Optional, before the row plan / gather of a step: queues the part of the forward's preparation that depends only on the

@@ -133,6 +133,26 @@ def test_eval_domain_with_mask(which):
             assert torch.equal(sd[k].cpu(), P[k]), k            # eval never touches the running statistics
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_eval_inference_epilogue_matches_unfolded_eval(precision):
+    """eval under torch.no_grad() (aread_call.inference: BatchNorm with running statistics + ReLU inside the expert GEMMs'
+    epilogue, no k_bn_act, H not kept) == eval with autograd enabled (the layer-by-layer expert path that keeps H for a
+    backward), on a many-row batch and on a ONE-row batch (BatchNorm skipped, layer.py:226)."""
+    fn, mk, seed = U.GOLDEN_MODELS["full"]
+    G, spec = U.load_golden(fn), mk()
+    model, _ = U.build_model(spec, seed, precision=precision)
+    model.eval()
+    model.bn_stats.uniform_(0.5, 1.5)                         # non-trivial running statistics
+    d = int(G["eval_with_mask/domain"])
+    mask = tmask(U.golden_masks(spec, G, "rand")[d])
+    x = torch.from_numpy(G["eval_with_mask/x"]).cuda()
+    for xb in (x, x[:1].contiguous()):
+        with torch.no_grad():
+            a = model(xb, mode="domain_with_mask", domain_i=d, current_mask=mask)
+        b = model(xb, mode="domain_with_mask", domain_i=d, current_mask=mask).detach()
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-6, atol=1e-7)
+
+
 @pytest.mark.parametrize("which", ["full", "tiny"])
 def test_wo_mask_warmup_step(which):
     fn, mk, seed = U.GOLDEN_MODELS[which]
