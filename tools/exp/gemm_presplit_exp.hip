@@ -1,0 +1,175 @@
+// Timing-only experiment (round 3): what does the expert-L1 forward GEMM cost when BOTH operands arrive as pre-split bf16 (hi, lo)
+// images by LDS-DMA (no fp32 -> (hi, lo) conversion, no ds_write in the k-loop), against converting the A tile in flight?
+// Results are not checked (operands are whatever the buffers hold); build: hipcc -O3 --offload-arch=gfx950 -o gemm_presplit_exp gemm_presplit_exp.hip
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+#include <stdlib.h>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ int bf3_off(int rows, int row, int plane) { return (plane * rows + (row ^ (2 * plane))) * 8; }
+
+// WG tile (32*WM) x (32*FN*WN), waves WM x WN, wave tile 32 x 32*FN; NB LDS buffers
+template <int WM, int WN, int FN, int PRESPLIT, int NB>
+__global__ __launch_bounds__(64 * WM * WN) void k_exp(const float* __restrict__ A, const __bf16* __restrict__ Aimg, const __bf16* __restrict__ Wimg,
+                                                      float* __restrict__ C, int M, int N, int K, int nx, int ny) {
+    constexpr int NT = 64 * WM * WN, TM = 32 * WM, TN = 32 * FN * WN;
+    constexpr int A_EL = TM * 32, W_EL = TN * 32;
+    constexpr int UA = (TM * 4 / NT) > 0 ? (TM * 4 / NT) : 1, UAD = (TM * 8 + NT - 1) / NT, UW = (TN * 8 + NT - 1) / NT;
+    __shared__ __attribute__((aligned(1024))) char s_lds[NB * 2 * (A_EL + W_EL) * 2];
+    __bf16* Ab = (__bf16*)s_lds;
+    __bf16* Wb = Ab + NB * 2 * A_EL;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WN, wc = wave - wr * WN, l31 = lane & 31, lh = lane >> 5;
+    const int KS = K >> 5;
+    for (int t = blockIdx.x; t < nx * ny; t += gridDim.x) {
+        const int xcd = t & 7, slot = t >> 3;
+        int bx = slot % nx, by = (slot / nx) * 8 + xcd;
+        if (by >= ny) { bx = t % nx; by = t / nx; }
+        const int m0 = by * TM;
+        const __bf16* wimg = Wimg + (int64_t)bx * KS * 2 * W_EL;
+        const __bf16* aimg = Aimg + (int64_t)by * KS * 2 * A_EL;
+        f32x16 acc[FN];
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        float4 av[UA][2];
+        auto loadA = [&](int s) {
+#pragma unroll
+            for (int u = 0; u < UA; ++u) {
+                const int idx = tid + u * NT, row = idx >> 2, plane = idx & 3;
+                const int m = m0 + row < M ? m0 + row : M - 1;
+                const float* src = A + (int64_t)m * K + s * 32 + plane * 8;
+                av[u][0] = *(const float4*)src; av[u][1] = *(const float4*)(src + 4);
+            }
+        };
+        auto storeA = [&](int buf) {
+            __bf16* Ah = Ab + buf * 2 * A_EL; __bf16* Al = Ah + A_EL;
+#pragma unroll
+            for (int u = 0; u < UA; ++u) {
+                const int idx = tid + u * NT, row = idx >> 2, plane = idx & 3;
+                const float x[8] = {av[u][0].x, av[u][0].y, av[u][0].z, av[u][0].w, av[u][1].x, av[u][1].y, av[u][1].z, av[u][1].w};
+                bf16x8 h, l;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { h[e] = (__bf16)x[e]; l[e] = (__bf16)(x[e] - (float)h[e]); }
+                const int o = bf3_off(TM, row, plane);
+                *(bf16x8*)(Ah + o) = h; *(bf16x8*)(Al + o) = l;
+            }
+        };
+        auto dma = [&](const __bf16* img, int s, __bf16* dstb, int el, int pieces, int U) {
+            const char* src = (const char*)(img + (int64_t)s * 2 * el);
+            char* dst = (char*)dstb;
+            for (int q = 0; q < U; ++q) {
+                const int piece = q * NT + wave * 64;
+                if (piece >= pieces) break;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (int64_t)(piece + lane) * 16),
+                                                 (__attribute__((address_space(3))) void*)(dst + piece * 16), 16, 0, 0);
+            }
+        };
+        const int a_row = wr * 32 + l31, w_row = wc * 32 * FN + l31;
+        // prologue: NB-1 stages in flight
+        for (int s = 0; s < NB - 1 && s < KS; ++s) {
+            dma(wimg, s, Wb + s * 2 * W_EL, W_EL, TN * 8, UW);
+            if (PRESPLIT) dma(aimg, s, Ab + s * 2 * A_EL, A_EL, TM * 8, UAD);
+        }
+        if (!PRESPLIT) { loadA(0); storeA(0); if (KS > 1) loadA(1); }
+        if (NB == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NB - 2) * (UW + (PRESPLIT ? UAD : 0))) : "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int s = 0; s < KS; ++s) {
+            const int cur = s % NB, nxt = (s + NB - 1) % NB;
+            const int sp = s + NB - 1 < KS ? s + NB - 1 : KS - 1;        // (clamped repeats keep the vmcnt arithmetic constant)
+            dma(wimg, sp, Wb + nxt * 2 * W_EL, W_EL, TN * 8, UW);
+            if (PRESPLIT) dma(aimg, sp, Ab + nxt * 2 * A_EL, A_EL, TM * 8, UAD);
+            const __bf16* Ah = Ab + (PRESPLIT ? cur : (s & 1)) * 2 * A_EL; const __bf16* Al = Ah + A_EL;
+            const __bf16* Wh = Wb + cur * 2 * W_EL; const __bf16* Wl = Wh + W_EL;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int plane = lh + 2 * kk;
+                const bf16x8 ah = *(const bf16x8*)(Ah + bf3_off(TM, a_row, plane));
+                const bf16x8 al = *(const bf16x8*)(Al + bf3_off(TM, a_row, plane));
+#pragma unroll
+                for (int i = 0; i < FN; ++i) {
+                    const bf16x8 wh = *(const bf16x8*)(Wh + bf3_off(TN, w_row + 32 * i, plane));
+                    const bf16x8 wl = *(const bf16x8*)(Wl + bf3_off(TN, w_row + 32 * i, plane));
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc[i], 0, 0, 0);
+                }
+            }
+            if (!PRESPLIT) {
+                if (s + 1 < KS) storeA((s + 1) & 1);
+                loadA(s + 2 < KS ? s + 2 : KS - 1);
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * UA + (NB - 2) * UW) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NB - 2) * (UW + UAD)) : "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+            float* c0 = C + (int64_t)(m0 + wr * 32 + 4 * lh) * N + bx * TN + wc * 32 * FN + 32 * i + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wr * 32 + 4 * lh + 8 * (r >> 2) + (r & 3);
+                if (m < M) c0[(int64_t)(8 * (r >> 2) + (r & 3)) * N] = acc[i][r];
+            }
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+template <int WM, int WN, int FN, int PRESPLIT, int NB>
+static void run(const char* name, const float* A, const __bf16* Aimg, const __bf16* Wimg, float* C, int M, int N, int K, int per_cu) {
+    constexpr int TM = 32 * WM, TN = 32 * FN * WN;
+    const int nx = N / TN, ny = (M + TM - 1) / TM;
+    int grid = per_cu * 256;
+    if (grid > nx * ny) grid = nx * ny;
+    grid = grid / 8 * 8;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((k_exp<WM, WN, FN, PRESPLIT, NB>), dim3(grid), dim3(64 * WM * WN), 0, 0, A, Aimg, Wimg, C, M, N, K, nx, ny);
+    float best = 1e9f, sum = 0.f;
+    for (int rep = 0; rep < 5; ++rep) {
+        hipEventRecord(e0, 0);
+        for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((k_exp<WM, WN, FN, PRESPLIT, NB>), dim3(grid), dim3(64 * WM * WN), 0, 0, A, Aimg, Wimg, C, M, N, K, nx, ny);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        const float us = ms * 1000.f / 20.f;
+        if (us < best) best = us;
+        sum += us;
+    }
+    hipError_t err = hipGetLastError();
+    printf("%-44s tile %3dx%3d  %d thr  grid %4d (tiles %4d)  M=%d N=%d K=%d : %7.2f us (min %.2f) %s\n", name, TM, TN, 64 * WM * WN, grid, nx * ny, M, N, K,
+           sum / 5, best, err == hipSuccess ? "" : hipGetErrorString(err));
+}
+
+int main() {
+    const int M = 9728;
+    float *A, *C; __bf16 *Aimg, *Wimg;
+    hipMalloc(&A, (size_t)M * 1024 * 4); hipMalloc(&C, (size_t)M * 1024 * 4);
+    hipMalloc(&Aimg, (size_t)(M + 256) * 1024 * 4); hipMalloc(&Wimg, (size_t)1024 * 1024 * 4);
+    hipMemset(A, 0x3c, (size_t)M * 1024 * 4); hipMemset(Aimg, 0x3c, (size_t)(M + 256) * 1024 * 4); hipMemset(Wimg, 0x3c, (size_t)1024 * 1024 * 4);
+    printf("== expert L1 forward shape (N 1024, K 288)\n");
+    run<4, 2, 2, 0, 2>("A converted in flight, 2 buffers", A, Aimg, Wimg, C, M, 1024, 288, 2);
+    run<4, 2, 2, 1, 2>("A pre-split by DMA, 2 buffers", A, Aimg, Wimg, C, M, 1024, 288, 2);
+    run<4, 2, 2, 1, 3>("A pre-split by DMA, 3 buffers (1 WG/CU)", A, Aimg, Wimg, C, M, 1024, 288, 1);
+    run<2, 2, 2, 0, 2>("A converted, 64x128 tiles, 2 buffers", A, Aimg, Wimg, C, M, 1024, 288, 3);
+    run<2, 2, 2, 1, 2>("A pre-split, 64x128 tiles, 2 buffers", A, Aimg, Wimg, C, M, 1024, 288, 3);
+    run<2, 2, 2, 1, 3>("A pre-split, 64x128 tiles, 3 buffers", A, Aimg, Wimg, C, M, 1024, 288, 2);
+    run<2, 2, 2, 1, 4>("A pre-split, 64x128 tiles, 4 buffers", A, Aimg, Wimg, C, M, 1024, 288, 2);
+    run<2, 4, 2, 1, 2>("A pre-split, 64x256 tiles, 8 waves, 2 buf", A, Aimg, Wimg, C, M, 1024, 288, 2);
+    run<4, 4, 2, 1, 2>("A pre-split, 128x256 tiles, 16 waves, 2 buf", A, Aimg, Wimg, C, M, 1024, 288, 1);
+    printf("== expert L1 dgrad shape (N 288 -> 256 here, K 1024)\n");
+    run<4, 2, 2, 0, 2>("A converted in flight, 2 buffers", A, Aimg, Wimg, C, M, 256, 1024, 2);
+    run<4, 2, 2, 1, 2>("A pre-split by DMA, 2 buffers", A, Aimg, Wimg, C, M, 256, 1024, 2);
+    run<2, 2, 2, 1, 3>("A pre-split, 64x128 tiles, 3 buffers", A, Aimg, Wimg, C, M, 256, 1024, 2);
+    run<2, 2, 2, 1, 4>("A pre-split, 64x128 tiles, 4 buffers", A, Aimg, Wimg, C, M, 256, 1024, 2);
+    printf("== expert L2 forward shape as one group (N 128, K 256)\n");
+    run<2, 2, 2, 0, 2>("A converted, 64x128 tiles", A, Aimg, Wimg, C, M * 4, 128, 256, 3);
+    run<2, 2, 2, 1, 3>("A pre-split, 64x128 tiles, 3 buffers", A, Aimg, Wimg, C, M * 4, 128, 256, 2);
+    return 0;
+}
