@@ -483,7 +483,7 @@ def _time_kernel(fn, iters=30, warm=3):
 
 def _pmc_traffic(kernel):
     """HBM bytes per launch from the committed rocprofv3 --pmc summary (profiles/), if present."""
-    for name in ("r02_pmc_roofline_kernels.json", "r01_pmc_roofline_kernels.json"):
+    for name in ("r03_pmc_roofline_kernels.json", "r02_pmc_roofline_kernels.json", "r01_pmc_roofline_kernels.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
@@ -495,7 +495,7 @@ def _pmc_traffic(kernel):
 def _family_share():
     """share of the step's kernel time taken by the split-bf16 GEMM family, from the committed rocprofv3 summary"""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_kernel_family_share.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r03_kernel_family_share.json")) as f:
             return json.load(f)
     except Exception:                                                # noqa: BLE001
         return None
