@@ -14,6 +14,7 @@ import ctypes as C
 from collections import OrderedDict
 
 import numpy as np
+import os
 import torch
 from torch import nn
 
@@ -117,14 +118,23 @@ class _AreadFn(torch.autograd.Function):
     def backward(ctx, dprobs):
         model, st = ctx.model, ctx.st
         dprobs = dprobs.contiguous()
-        # the flat dense gradient goes straight into the model's gradient arena when no .grad is held yet (the usual
-        # zero_grad -> backward -> step loop); every parameter's .grad is a cached view of that arena
+        # The flat dense gradient lives in the model's gradient arena (every parameter's .grad is a cached view of it):
+        #   no gradient held yet (zero_grad -> backward)      : the library writes the arena
+        #   gradients held in the arena (the regulariser's node ran first, or gradient accumulation over several backwards):
+        #                                                       the library ADDS onto the arena (aread_call.grads_init)
+        #   gradients held elsewhere (a buffer adopted from train_step): a temporary, added by torch
         fresh = model._grads_fresh()
-        grads = model._grad_arena(st.e.device) if fresh else torch.empty_like(model.dense)
+        arena = model._grad_arena(st.e.device)
+        in_place = fresh or model._gflat is arena
+        grads = arena if in_place else torch.empty_like(model.dense)
         de = model._de_arena(st.e)
-        L.check(L.lib().aread_backward(model._handle, C.byref(st.call), L.ptr(st.e), L.ptr(dprobs), L.ptr(grads),
-                                       L.ptr(de), L.stream()))
-        model._accumulate_dense(grads, ctx.present, take=True, in_arena=fresh)
+        st.call.grads_init = 0 if fresh or not in_place else 1
+        try:
+            L.check(L.lib().aread_backward(model._handle, C.byref(st.call), L.ptr(st.e), L.ptr(dprobs), L.ptr(grads),
+                                           L.ptr(de), L.stream()))
+        finally:
+            st.call.grads_init = 0
+        model._accumulate_dense(grads, ctx.present, take=True, in_arena=in_place)
         gtab = torch.zeros(ctx.table_shape, dtype=torch.float32, device=de.device)
         model.embedding.scatter_grad(st.x, de, gtab, st.plan.sample_row)
         return gtab, None, None, None, None, None
@@ -153,7 +163,13 @@ class _RegFn(torch.autograd.Function):
         g = gout.reshape(-1)[:1].contiguous()      # scalar scale of the regulariser in the caller's loss: stays on the device
         gtab = torch.empty_like(table)
         L.check(L.lib().aread_l2_table_dev(L.ptr(table), table.numel(), model.l2_reg_embedding, L.ptr(g), L.ptr(gtab), L.stream()))
-        model._accumulate_dense(model._l2_coef2(table.device) * model.dense * g, model._reg_present, take=True)
+        if model._grads_fresh():               # (this node runs before the forward's: the regulariser was added to the loss last)
+            arena = model._grad_arena(table.device)
+            torch.mul(model._l2_coef2(table.device), model.dense, out=arena)
+            arena.mul_(g)
+            model._accumulate_dense(arena, model._reg_present, take=True, in_arena=True)
+        else:
+            model._accumulate_dense(model._l2_coef2(table.device) * model.dense * g, model._reg_present, take=True)
         return gtab, None, None
 
 
@@ -339,6 +355,7 @@ class AREAD(HempMixin, nn.Module):
             p.data = self._view_of(self.dense, t)
             p.grad = None
         self._gflat, self._garena, self._gviews, self._dearena, self._ext_views = None, None, None, None, None
+        self.__dict__["_ghave"] = 0
         self._mask_cache = {}
         return self
 
@@ -354,15 +371,72 @@ class AREAD(HempMixin, nn.Module):
             if p.grad is not None:
                 if set_to_none:
                     p.grad = None
-                else:
-                    p.grad.detach_().zero_()
+                else:                                   # (the gradients are views of one flat buffer: no detach_() on a view)
+                    g = p.grad
+                    if g.grad_fn is not None:
+                        p.grad = g = g.detach()
+                    g.zero_()
+        # what the module knows about the dense parameters' .grad without reading 300 attributes: a bit per parameter that holds a
+        # gradient view THIS module assigned since the last all-None state; None = unknown (grads zeroed in place, external edits)
+        self.__dict__["_ghave"] = 0 if set_to_none else None
+
+    _GRAD_SCAN = os.environ.get("AREAD_GRAD_SCAN", "0") == "1"     # 1: always read every parameter's .grad (no bookkeeping shortcuts)
+
+    @staticmethod
+    def _bits(present):
+        b = 0
+        for i, pres in enumerate(present):
+            if pres:
+                b |= 1 << i
+        return b
+
+    def _present_bits(self, present):
+        """bit mask + index list of a presence list, cached by the list object (the lists themselves are cached per mask version)"""
+        c = self.__dict__.setdefault("_pbits", {})
+        ent = c.get(id(present))
+        if ent is None or ent[0] is not present:
+            if len(c) > 256:
+                c.clear()
+            ent = (present, self._bits(present), [i for i, pres in enumerate(present) if pres])
+            c[id(present)] = ent
+        return ent[1], ent[2]
 
     def _grads_fresh(self):
-        """no dense parameter holds a gradient (zero_grad(set_to_none=True) or a new model)"""
-        for p in self._dparams:
+        """no dense parameter holds a gradient (zero_grad(set_to_none=True) or a new model).
+        Fast path: the module's own record (`_ghave`), confirmed on one parameter -- model.zero_grad() and the module's own
+        assignments keep it exact; an optimizer's zero_grad() is noticed on the sampled parameter and answered by a full scan."""
+        have = self.__dict__.get("_ghave")
+        dp = self._dparams
+        if have is not None and not self._GRAD_SCAN:
+            if have == 0:
+                if dp[0].grad is None and dp[-1].grad is None:
+                    return True
+            else:
+                k = (have & -have).bit_length() - 1           # a parameter this module gave a gradient to
+                if dp[k].grad is not None:
+                    return False
+        for p in dp:                                            # unknown state (or the sample disagreed): look at everything
             if p.grad is not None:
+                self.__dict__["_ghave"] = None
                 return False
+        self.__dict__["_ghave"] = 0
         return True
+
+    def _grad_presence(self):
+        """bool array: which dense parameters hold a gradient right now (what an optimizer's `p.grad is None` test sees)"""
+        have = self.__dict__.get("_ghave")
+        dp = self._dparams
+        if have is not None and have != 0 and not self._GRAD_SCAN:
+            k = (have & -have).bit_length() - 1
+            if dp[k].grad is not None:                          # the record is live (nobody set the gradients to None behind it)
+                c = self.__dict__.setdefault("_hbits", {})
+                arr = c.get(have)
+                if arr is None:
+                    if len(c) > 256:
+                        c.clear()
+                    arr = c[have] = np.array([(have >> i) & 1 for i in range(len(dp))], dtype=bool)
+                return arr
+        return np.array([p.grad is not None for p in dp], dtype=bool)
 
     def _grad_arena(self, device):
         """one flat gradient buffer per model, reused by every backward; `_gviews[i]` is parameter i's view of it"""
@@ -380,11 +454,23 @@ class AREAD(HempMixin, nn.Module):
         """Add a flat gradient contribution.  Tensors marked present get `.grad` (a view of the flat gradient buffer);
         the others keep grad=None exactly as the reference's autograd leaves them (Adam then skips them).
         in_arena: `flat` IS the model's gradient arena and no gradient was held before (the caller checked)."""
+        dp = self._dparams
         if in_arena:
+            # `flat` is the arena and already holds the sum (written by a fresh backward, or added onto in place)
             self._gflat, views = flat, self._gviews
-            for p, v, pres in zip(self._dparams, views, present):
-                if pres:
-                    p.grad = v
+            bits, idx = self._present_bits(present)
+            have = self.__dict__.get("_ghave")
+            if have is not None and not self._GRAD_SCAN:
+                need = bits & ~have
+                if need:
+                    for i in idx:
+                        if (need >> i) & 1:
+                            dp[i].grad = views[i]
+                self.__dict__["_ghave"] = have | bits
+            else:
+                for i in idx:
+                    if dp[i].grad is None:
+                        dp[i].grad = views[i]
             return
         fresh = self._grads_fresh()
         if fresh and take:                      # adopt the caller's buffer (train_step's persistent bufs['gdense'], a fresh temporary)
@@ -402,9 +488,20 @@ class AREAD(HempMixin, nn.Module):
             if self._ext_views is None or self._ext_views[0] != key:
                 self._ext_views = (key, [self._view_of(self._gflat, t) for t in self._ptensors])
             views = self._ext_views[1]
-        for p, v, pres in zip(self._dparams, views, present):
-            if pres and p.grad is None:
-                p.grad = v
+        bits, idx = self._present_bits(present)
+        have = self.__dict__.get("_ghave")
+        if have is not None and not self._GRAD_SCAN:
+            # the module knows which parameters already hold a view of this buffer: only the new ones are touched
+            need = bits & ~have
+            if need:
+                for i in idx:
+                    if (need >> i) & 1:
+                        dp[i].grad = views[i]
+            self.__dict__["_ghave"] = have | bits
+            return
+        for i in idx:
+            if dp[i].grad is None:
+                dp[i].grad = views[i]
 
     def _presence(self, mode_id, masks):
         """Which dense tensors are on a gradient path of a forward call (what the reference's autograd would reach)."""
@@ -919,6 +1016,7 @@ class AREAD(HempMixin, nn.Module):
         if set_grads:
             for p in self._dparams:
                 p.grad = None
+            self.__dict__["_ghave"] = 0
             present = [a or b for a, b in zip(self._presence(0, self.domain_mask), self._reg_present)] if with_reg \
                 else self._presence(0, self.domain_mask)
             self._accumulate_dense(bufs["gdense"], present, take=True)

@@ -220,6 +220,11 @@ extern "C" int aread_debug_phase_times(float* out_ms, int n) {
 
 static int g_fused_mode = -1;        // AREAD_FUSED_TOWERS: 0 = layer-by-layer launches (default: measured faster), 1 = fused tower forward
 extern int g_plan_single;          // plan.hip
+static int g_two_hop_nt = -1;      // AREAD_TWO_HOP_NT / aread_debug_set("two_hop_nt", v): segments of more tiles merge their BatchNorm statistics in two hops
+static int two_hop_nt() {
+    if (g_two_hop_nt < 0) { const char* e = getenv("AREAD_TWO_HOP_NT"); g_two_hop_nt = e ? atoi(e) : TF_TWO_HOP_NT; }
+    return g_two_hop_nt;
+}
 static int g_fused_act_bn = -1;    // AREAD_FUSED_ACT_BN / aread_debug_set("fused_act_bn", v): k_act_bn_bwd for the expert layers (A/B)
 static int g_n_cu = 0;
 static long long g_fused_fwd_calls = 0, g_fused_bwd_calls = 0;   // aread_debug_get: the tests check that the fused kernels really ran
@@ -288,6 +293,7 @@ static int tower_fused_fwd(Ctx& x, bool want_gates) {
     const float* P = x.params;
     TFwdP p = {};
     p.n_level = cfg.n_level; p.n_layers = m->towers[0].n_layers; p.train = c->train; p.mode = c->mode;
+    p.two_hop_nt = two_hop_nt();
     p.seed = c->drop_seed; p.thr = x.thr; p.keep_scale = x.keep_scale;
     for (int l = 0; l < cfg.n_level; ++l) {
         p.n_t[l] = cfg.n_tower[l]; p.mask_off[l] = m->mask_off[l]; p.gate_off[l] = m->gate_off[l];
@@ -304,6 +310,7 @@ static int tower_fused_fwd(Ctx& x, bool want_gates) {
             T.rmean = c->stats + L.rmean; T.rvar = c->stats + L.rvar;
             T.H = ws + lw.H; T.Act = ws + lw.Act; T.part = ws + lw.part; T.mean = ws + lw.mean; T.rstd = ws + lw.rstd; T.var = ws + lw.var;
             T.tags = (tf_u64*)(ws + lw.tag_f);
+            T.fin = (tf_u64*)(ws + lw.fin_f);
         }
     }
     const int nle = m->experts.n_layers;
@@ -395,6 +402,7 @@ static int tower_fused_bwd(Ctx& x, float* grads) {
     const int LL = cfg.n_level - 1, nle = m->experts.n_layers;
     TBwdP p = {};
     p.n_level = cfg.n_level; p.n_layers = m->towers[0].n_layers; p.train = c->train; p.mode = c->mode;
+    p.two_hop_nt = two_hop_nt();
     p.seed = c->drop_seed; p.thr = x.thr; p.keep_scale = x.keep_scale;
     for (int l = 0; l < cfg.n_level; ++l) {
         p.n_t[l] = cfg.n_tower[l]; p.mask_off[l] = m->mask_off[l]; p.gate_off[l] = m->gate_off[l];
@@ -411,6 +419,7 @@ static int tower_fused_bwd(Ctx& x, float* grads) {
             T.H = ws + lw.H; T.mean = ws + lw.mean; T.rstd = ws + lw.rstd;
             T.dH = ws + lw.dAct; T.bpart = ws + lw.bpart; T.cpart = ws + lw.cpart;
             T.tags = (tf_u64*)(ws + lw.tag_b);
+            T.fin = (tf_u64*)(ws + lw.fin_b);
         }
     }
     p.X = ws + x.w.ex[nle - 1].Act; p.n_exp = cfg.n_expert; p.xw = m->experts.L[nle - 1].out_dim; p.dX = ws + x.w.ex[nle - 1].dAct;
@@ -778,6 +787,8 @@ static int layer_bwd(Ctx& x, const LayerL& L, const LayerWs& lw, const float* in
         ActBnBwdP q = {};
         q.a = a; q.cpart = ws + lw.cpart;
         q.tags = (tf_u64*)(ws + lw.tag_b);
+        q.fin = (tf_u64*)(ws + lw.fin_b);
+        q.two_hop_nt = two_hop_nt();
         q.err = (unsigned*)(ws + x.w.tf_sync) + AREAD_MAX_LEVEL * AREAD_MAX_LAYER * MAX_SEG;
         LAUNCH(k_act_bn_bwd, dim3(x.n_tiles, n_chunks), dim3(256), q);
     } else {
@@ -1060,6 +1071,7 @@ extern "C" int aread_debug_set(const char* key, int value) {
     if (!strcmp(key, "fused_towers")) g_fused_mode = value;
     else if (!strcmp(key, "fused_towers_bwd")) g_fused_bwd = value;
     else if (!strcmp(key, "fused_act_bn")) g_fused_act_bn = value;
+    else if (!strcmp(key, "two_hop_nt")) g_two_hop_nt = value;
     else if (!strcmp(key, "plan_single")) g_plan_single = value;
     else if (!strcmp(key, "tf_stamps")) g_tf_stamps = value;
     else if (!strcmp(key, "phase_events")) g_phase_on = value;

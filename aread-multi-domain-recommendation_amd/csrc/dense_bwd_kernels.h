@@ -479,6 +479,8 @@ struct ActBnBwdP {
     float* cpart;                       // [n_tiles][ncols]
     tf_u64* tags;                       // [n_tiles][ncols][2] data-tagged (sum dyhat, sum dyhat*xhat) granules, zeroed per step
     unsigned* err;
+    tf_u64* fin;                        // [MAX_SEG][ncols][2] the two sums of a long segment, published by the granule's owner tile
+    int two_hop_nt;                     // segments of more tiles take the two-hop merge
 };
 
 __global__ __launch_bounds__(256) void k_act_bn_bwd(const ActBnBwdP q) {
@@ -554,40 +556,75 @@ __global__ __launch_bounds__(256) void k_act_bn_bwd(const ActBnBwdP q) {
     }
     // ---- 2. hand-off: sweep the data-tagged granules of the segment's tiles for this chunk's columns ------------------------
     const int ncol_here = (p.ncols - c0 < 64 ? p.ncols - c0 : 64) * 2;
-    if (sync_now) {
+    const int nt_seg = (cnt_ + TILE_M - 1) / TILE_M;
+    if (sync_now && nt_seg > q.two_hop_nt) {
+        // long segment (a one-domain batch: 128 tiles): two hops instead of every tile summing every tile's partials (tower_fused.h).
+        // Tile i of the segment owns the granules v = i (mod nt) of this column chunk; one wave per owned granule adds the nt
+        // partials (lane = tile, then a butterfly, lower lane first) and publishes the sum; then 128 threads read the 128 sums.
+        const int t0 = p.r.seg_start[seg] / TILE_M, nt = nt_seg, ti = tile - t0;
+        const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+        tf_u64* fin = q.fin + ((int64_t)seg * p.ncols + c0) * 2;
+        for (int v = ti + nt * wv; v < ncol_here; v += nt * 4) {                   // (wave-uniform)
+            const tf_u64* src = q.tags + ((int64_t)t0 * p.ncols + c0) * 2 + v;
+            float acc = 0.f;
+            for (int t = ln; t < nt; t += 64) {
+                tf_u64 x;
+                unsigned spins = 0;
+                do { x = __hip_atomic_load(src + (int64_t)t * p.ncols * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                while ((unsigned)(x >> 32) != TF_TAG && ++spins < (1u << 22));
+                if ((unsigned)(x >> 32) != TF_TAG) __hip_atomic_store(q.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                acc += __uint_as_float((unsigned)x);
+            }
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const float u = __shfl_xor(acc, o);
+                acc = (ln & o) ? u + acc : acc + u;
+            }
+            if (ln == 0) __hip_atomic_store(fin + v, ((tf_u64)TF_TAG << 32) | __float_as_uint(acc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (threadIdx.x < 128) {
+            float sum = 0.f;
+            if ((int)threadIdx.x < ncol_here) {
+                tf_u64 x;
+                unsigned spins = 0;
+                do { x = __hip_atomic_load(fin + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                while ((unsigned)(x >> 32) != TF_TAG && ++spins < (1u << 22));
+                if ((unsigned)(x >> 32) != TF_TAG) __hip_atomic_store(q.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sum = __uint_as_float((unsigned)x);
+            }
+            s_sum[threadIdx.x] = sum;
+        }
+        __syncthreads();
+    } else if (sync_now) {
         const int t0 = p.r.seg_start[seg] / TILE_M, nt = (cnt_ + TILE_M - 1) / TILE_M;
         // per-segment sums of this block's 64 columns, the order of k_bn_bwd_apply: two interleaved halves, then combined
         const int v = threadIdx.x & 127, half = threadIdx.x >> 7;
         float acc = 0.f;
         if (v < ncol_here) {
             const tf_u64* src = q.tags + ((int64_t)t0 * p.ncols + c0) * 2 + v;       // granule (column v/2, component v&1) of tile t0
-            float b[12];
-            bool have[12];
+            // 12 partials in flight per round (a one-domain batch of 128 tiles takes six rounds), summed in tile order
+            for (int kb = 0; half + 2 * kb < nt; kb += 12) {
+                float b[12];
+                bool have[12];
 #pragma unroll
-            for (int k = 0; k < 12; ++k) { b[k] = 0.f; have[k] = half + 2 * k >= nt; }
-            for (unsigned spins = 0;;) {
-                bool all = true;
+                for (int k = 0; k < 12; ++k) { b[k] = 0.f; have[k] = half + 2 * (kb + k) >= nt; }
+                for (unsigned spins = 0;;) {
+                    bool all = true;
 #pragma unroll
-                for (int k = 0; k < 12; ++k) {
-                    if (!have[k]) {
-                        const tf_u64 x = __hip_atomic_load(src + (int64_t)(half + 2 * k) * p.ncols * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        have[k] = (unsigned)(x >> 32) == TF_TAG;
-                        b[k] = __uint_as_float((unsigned)x);
+                    for (int k = 0; k < 12; ++k) {
+                        if (!have[k]) {
+                            const tf_u64 x = __hip_atomic_load(src + (int64_t)(half + 2 * (kb + k)) * p.ncols * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            have[k] = (unsigned)(x >> 32) == TF_TAG;
+                            b[k] = __uint_as_float((unsigned)x);
+                        }
+                        all = all && have[k];
                     }
-                    all = all && have[k];
+                    if (all) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 22)) { __hip_atomic_store(q.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                 }
-                if (all) break;
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1u << 22)) { __hip_atomic_store(q.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            }
 #pragma unroll
-            for (int k = 0; k < 12; ++k) acc += b[k];
-            for (int t = half + 24; t < nt; t += 2) {
-                tf_u64 x;
-                unsigned spins = 0;
-                do { x = __hip_atomic_load(src + (int64_t)t * p.ncols * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-                while ((unsigned)(x >> 32) != TF_TAG && ++spins < (1u << 22));
-                acc += __uint_as_float((unsigned)x);
+                for (int k = 0; k < 12; ++k) acc += b[k];
             }
         }
         s_half[half][v] = acc;

@@ -221,34 +221,28 @@ __global__ __launch_bounds__(256) void k_bn_act(const BnActP p) {
         if (act && p.level >= 0) act = active_level(p.mp, p.level)[seg * MAX_TOWER + cc / p.h] != 0;
         float n = 0.f, mean = 0.f, m2 = 0.f;
         if (act && cnt > 1 && p.train) {
-            // the first 24 tiles of the group in flight at once (six per thread): the loop below used to pay one global round trip
-            // per tile before the apply pass could start (same arithmetic, same order)
-            float nbv[6], mbv[6], m2v[6];
+            // six tiles of the group in flight per round (the loop used to pay one global round trip per tile before the apply
+            // pass could start; a one-domain batch of 128 tiles takes six rounds): same arithmetic, same order
+            for (int kb = 0; tg + 4 * kb < nt; kb += 6) {
+                float nbv[6], mbv[6], m2v[6];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                const int t = tg + 4 * k;
-                nbv[k] = 0.f; mbv[k] = 0.f; m2v[k] = 0.f;
-                if (t < nt) {
-                    const float2 pp = *(const float2*)(p.part + ((int64_t)(t0 + t) * p.ncols + cc) * 2);
-                    nbv[k] = (float)p.r.tile_valid[t0 + t]; mbv[k] = pp.x; m2v[k] = pp.y;
+                for (int k = 0; k < 6; ++k) {
+                    const int t = tg + 4 * (kb + k);
+                    nbv[k] = 0.f; mbv[k] = 0.f; m2v[k] = 0.f;
+                    if (t < nt) {
+                        const float2 pp = *(const float2*)(p.part + ((int64_t)(t0 + t) * p.ncols + cc) * 2);
+                        nbv[k] = (float)p.r.tile_valid[t0 + t]; mbv[k] = pp.x; m2v[k] = pp.y;
+                    }
                 }
-            }
 #pragma unroll
-            for (int k = 0; k < 6; ++k)
-                if (tg + 4 * k < nt) {
-                    const float nb = nbv[k];
-                    const float tot = n + nb, delta = mbv[k] - mean;
-                    mean += delta * (nb / tot);
-                    m2 += m2v[k] + delta * delta * (n * nb / tot);
-                    n = tot;
-                }
-            for (int t = tg + 24; t < nt; t += 4) {
-                const float* pp = p.part + ((int64_t)(t0 + t) * p.ncols + cc) * 2;
-                const float nb = (float)p.r.tile_valid[t0 + t], mb = pp[0], m2b = pp[1];
-                const float tot = n + nb, delta = mb - mean;
-                mean += delta * (nb / tot);
-                m2 += m2b + delta * delta * (n * nb / tot);
-                n = tot;
+                for (int k = 0; k < 6; ++k)
+                    if (tg + 4 * (kb + k) < nt) {
+                        const float nb = nbv[k];
+                        const float tot = n + nb, delta = mbv[k] - mean;
+                        mean += delta * (nb / tot);
+                        m2 += m2v[k] + delta * delta * (n * nb / tot);
+                        n = tot;
+                    }
             }
         }
         s_n[tg][cl] = n; s_m[tg][cl] = mean; s_q[tg][cl] = m2;

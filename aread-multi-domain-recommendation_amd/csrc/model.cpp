@@ -296,10 +296,14 @@ void ws_layout(const aread_model* m, int64_t B, int n_seg, WsLayout* w) {
             const LayerL& L = m->towers[l].L[j];
             w->tw[l][j].tag_f = take(&o, tiles * L.ncols * 4);
             w->tw[l][j].tag_b = take(&o, tiles * L.ncols * 4);
+            w->tw[l][j].fin_f = take(&o, (int64_t)MAX_SEG * L.ncols * 4);
+            w->tw[l][j].fin_b = take(&o, (int64_t)MAX_SEG * L.ncols * 4);
         }
     w->tf_tags_floats = o - w->tf_tags;
     for (int j = 0; j < m->experts.n_layers; ++j)            // k_act_bn_bwd (A/B only): right behind, one memset can cover both
         w->ex[j].tag_b = take(&o, tiles * m->experts.L[j].ncols * 4);
+    for (int j = 0; j < m->experts.n_layers; ++j)
+        w->ex[j].fin_b = take(&o, (int64_t)MAX_SEG * m->experts.L[j].ncols * 4);
     w->ab_tags_floats = o - w->tf_tags - w->tf_tags_floats;
     w->total = o;
 }

@@ -27,6 +27,7 @@ struct LayerWs {             // workspace of one layer (float offsets)
     int64_t wT;              // transposed weights [G][in][out] (split-bf16 dgrad wants k-contiguous operands)
     int64_t wimg_f, wimg_d;  // pre-tiled split-bf16 weight images for the wide GEMM (gemm_wide.h): forward, dgrad view
     int64_t tag_f = -1, tag_b = -1;   // tower layers: data-tagged hand-off granules of the fused kernels, [tiles][ncols][2] x 8 bytes
+    int64_t fin_f = -1, fin_b = -1;   // the finished per-segment pairs of a long segment's two-hop merge, [MAX_SEG][ncols][2] x 8 bytes
 };
 
 struct StackL {

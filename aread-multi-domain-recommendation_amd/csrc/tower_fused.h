@@ -34,6 +34,7 @@
 #define TF_SPIN_LIMIT (1u << 22)
 #define TF_MAX_SEG_TILES 256           // tiles of one segment whose row counts are cached in LDS
 #define TF_MERGE_Q 12                  // partial loads in flight per (column, tile group): covers segments of <= 24 tiles at two groups
+#define TF_TWO_HOP_NT 32               // default of AREAD_TWO_HOP_NT: segments of more tiles merge their statistics in two hops (owner per column, then all read the result)
 
 // the "tower t of this level is active for the tile's segment" bytes as a register bit mask: act[t] in an inner loop was a
 // dependent global load per item (the gate / mix / dot-product phases of both kernels spent most of their time waiting for it)
@@ -63,10 +64,11 @@ struct TFLayer {
     const float* rmean; const float* rvar;
     float* H; float* Act; float* part; float* mean; float* rstd; float* var;
     tf_u64* tags;                       // [n_tiles][ncols][2] data-tagged (mean, M2) granules of the in-kernel hand-off
+    tf_u64* fin;                        // [MAX_SEG][ncols][2] data-tagged (mean, rstd) of a long segment, published by the column's owner tile
 };
 
 struct TFwdP {
-    int n_level, n_layers, train, mode;
+    int n_level, n_layers, train, mode, two_hop_nt;
     uint32_t seed, thr; float keep_scale;
     TFLayer L[AREAD_MAX_LEVEL][AREAD_MAX_LAYER];
     int n_t[AREAD_MAX_LEVEL], mask_off[AREAD_MAX_LEVEL], gate_off[AREAD_MAX_LEVEL];
@@ -433,7 +435,68 @@ __global__ __launch_bounds__(TF_THREADS) void k_tower_fwd(const TFwdP p) {
                     *(float4*)(L.H + (row0 + mi * 16 + fr) * ncols + col) = make_float4(acc[u][mi][0], acc[u][mi][1], acc[u][mi][2], acc[u][mi][3]);
             }
             // ---- statistics of the segment -------------------------------------------------------------------------------
-            if (sync_stats) {
+            if (sync_stats && nt > p.two_hop_nt) {
+                TF_STAMP();                                  // H stores issued + poll
+                // Long segment (the reference's per-domain batches are ONE segment: 128 tiles at B = 8192): every tile merging every
+                // tile's partials is nt^2 granule loads per column -- 27 us per layer at 128 tiles.  Two hops instead: tile i of the
+                // segment owns the columns c = i (mod nt); one wave per owned column gathers the nt partials (lane = tile: Chan in
+                // lane order, then a butterfly whose pairs are combined lower lane first, so every lane ends with the same bits) and
+                // publishes the segment's (mean, rstd) as one tagged pair; then every tile picks up the ncols finished pairs.
+                // All tiles use the owner's numbers, so the statistics are identical across the segment by construction.
+                const int ti = tile - t0;
+                for (int c = ti + nt * wave; c < ncols; c += nt * TF_WAVES) {        // (wave-uniform)
+                    const bool on = act[c / out_w];
+                    float n = 0.f, mean = 0.f, m2 = 0.f;
+                    if (on) {
+                        for (int t = lane; t < nt; t += 64) {
+                            float mb = 0.f, qb = 0.f;
+                            for (unsigned spins = 0; !tf_get_tagged(L.tags + ((int64_t)(t0 + t) * ncols + c) * 2, mb, qb);) {
+                                __builtin_amdgcn_s_sleep(1);
+                                if (++spins > TF_SPIN_LIMIT) { __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                            }
+                            const float nb = t < TF_MAX_SEG_TILES ? s_tv[t] : (float)p.r.tile_valid[t0 + t];
+                            const float tot = n + nb, delta = mb - mean, rt = __builtin_amdgcn_rcpf(tot);
+                            mean += delta * (nb * rt);
+                            m2 += qb + delta * delta * (n * nb * rt);
+                            n = tot;
+                        }
+#pragma unroll
+                        for (int o = 1; o < 64; o <<= 1) {
+                            const float n2 = __shfl_xor(n, o), me2 = __shfl_xor(mean, o), q2 = __shfl_xor(m2, o);
+                            const bool hi = (lane & o) != 0;
+                            const float nA = hi ? n2 : n, mA = hi ? me2 : mean, qA = hi ? q2 : m2;
+                            const float nB = hi ? n : n2, mB = hi ? mean : me2, qB = hi ? m2 : q2;
+                            const float tot = nA + nB;
+                            mean = mA; m2 = qA;
+                            if (nB > 0.f) {
+                                const float delta = mB - mA, rt = __builtin_amdgcn_rcpf(tot);
+                                mean = mA + delta * (nB * rt);
+                                m2 = qA + qB + delta * delta * (nA * nB * rt);
+                            }
+                            n = tot;
+                        }
+                    }
+                    if (lane == 0) {
+                        float rstd = 1.f, var = 0.f;
+                        if (on) {
+                            var = m2 / (float)cnt;
+                            rstd = 1.0f / sqrtf(var + BN_EPS);
+                            tf_put_tagged(L.fin + ((int64_t)seg * ncols + c) * 2, mean, rstd);
+                        }
+                        const int64_t o = (int64_t)seg * ncols + c;
+                        L.mean[o] = mean; L.rstd[o] = rstd; L.var[o] = var;
+                    }
+                }
+                for (int c = tid; c < ncols; c += TF_THREADS) {
+                    float mean = 0.f, rstd = 1.f;
+                    if (act[c / out_w])
+                        for (unsigned spins = 0; !tf_get_tagged(L.fin + ((int64_t)seg * ncols + c) * 2, mean, rstd);) {
+                            __builtin_amdgcn_s_sleep(1);
+                            if (++spins > TF_SPIN_LIMIT) { __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                        }
+                    s_mean[c] = mean; s_rstd[c] = rstd;
+                }
+            } else if (sync_stats) {
                 TF_STAMP();                                  // H stores issued + poll
                 // merge the partials of the segment's tiles (Chan): item = (column, tile quarter q: tiles q, q+4, ...), every
                 // load of an item in flight at once, then the four quarters are combined in order -- the order of k_bn_act
@@ -444,43 +507,35 @@ __global__ __launch_bounds__(TF_THREADS) void k_tower_fwd(const TFwdP p) {
                     const int c = item % ncols, q = item / ncols;
                     float n = 0.f, mean = 0.f, m2 = 0.f;
                     if (item < nq * ncols && act[c / out_w]) {
-                        float mb[TF_MERGE_Q], qb[TF_MERGE_Q];
-                        bool have[TF_MERGE_Q];
+                        // TF_MERGE_Q partials of the item in flight per round (one round covers segments of <= nq*TF_MERGE_Q tiles; a
+                        // one-domain batch of 128 tiles takes three): merged in tile order whatever the round size
+                        for (int ib = 0; q + nq * ib < nt; ib += TF_MERGE_Q) {
+                            float mb[TF_MERGE_Q], qb[TF_MERGE_Q];
+                            bool have[TF_MERGE_Q];
 #pragma unroll
-                        for (int i = 0; i < TF_MERGE_Q; ++i) { mb[i] = 0.f; qb[i] = 0.f; have[i] = q + nq * i >= nt; }
-                        for (unsigned spins = 0;;) {             // sweep this item's granules until every tag matches
-                            bool all = true;
+                            for (int i = 0; i < TF_MERGE_Q; ++i) { mb[i] = 0.f; qb[i] = 0.f; have[i] = q + nq * (ib + i) >= nt; }
+                            for (unsigned spins = 0;;) {         // sweep this round's granules until every tag matches
+                                bool all = true;
 #pragma unroll
-                            for (int i = 0; i < TF_MERGE_Q; ++i) {
-                                if (!have[i]) have[i] = tf_get_tagged(L.tags + ((int64_t)(t0 + q + nq * i) * ncols + c) * 2, mb[i], qb[i]);
-                                all = all && have[i];
-                            }
-                            if (all) break;
-                            __builtin_amdgcn_s_sleep(1);
-                            if (++spins > TF_SPIN_LIMIT) { __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                        }
-#pragma unroll
-                        for (int i = 0; i < TF_MERGE_Q; ++i) {
-                            const int t = q + nq * i;
-                            if (t < nt) {
-                                const float nb = t < TF_MAX_SEG_TILES ? s_tv[t] : (float)p.r.tile_valid[t0 + t];
-                                const float tot = n + nb, delta = mb[i] - mean, rt = __builtin_amdgcn_rcpf(tot);
-                                mean += delta * (nb * rt);
-                                m2 += qb[i] + delta * delta * (n * nb * rt);
-                                n = tot;
-                            }
-                        }
-                        for (int t = q + nq * TF_MERGE_Q; t < nt; t += nq) {    // very long segments
-                            float mbx = 0.f, qbx = 0.f;
-                            for (unsigned spins = 0; !tf_get_tagged(L.tags + ((int64_t)(t0 + t) * ncols + c) * 2, mbx, qbx);) {
+                                for (int i = 0; i < TF_MERGE_Q; ++i) {
+                                    if (!have[i]) have[i] = tf_get_tagged(L.tags + ((int64_t)(t0 + q + nq * (ib + i)) * ncols + c) * 2, mb[i], qb[i]);
+                                    all = all && have[i];
+                                }
+                                if (all) break;
                                 __builtin_amdgcn_s_sleep(1);
                                 if (++spins > TF_SPIN_LIMIT) { __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                             }
-                            const float nb = t < TF_MAX_SEG_TILES ? s_tv[t] : (float)p.r.tile_valid[t0 + t];
-                            const float tot = n + nb, delta = mbx - mean, rt = __builtin_amdgcn_rcpf(tot);
-                            mean += delta * (nb * rt);
-                            m2 += qbx + delta * delta * (n * nb * rt);
-                            n = tot;
+#pragma unroll
+                            for (int i = 0; i < TF_MERGE_Q; ++i) {
+                                const int t = q + nq * (ib + i);
+                                if (t < nt) {
+                                    const float nb = t < TF_MAX_SEG_TILES ? s_tv[t] : (float)p.r.tile_valid[t0 + t];
+                                    const float tot = n + nb, delta = mb[i] - mean, rt = __builtin_amdgcn_rcpf(tot);
+                                    mean += delta * (nb * rt);
+                                    m2 += qb[i] + delta * delta * (n * nb * rt);
+                                    n = tot;
+                                }
+                            }
                         }
                     }
                     if (item < nq * ncols) { s_cn[q][c] = n; s_cm[q][c] = mean; s_cq[q][c] = m2; }

@@ -24,10 +24,11 @@ struct TBLayer {
     const float* H; const float* mean; const float* rstd;
     float* dH; float* bpart; float* cpart;
     tf_u64* tags;                       // [n_tiles][ncols][2] data-tagged (sum dyhat, sum dyhat*xhat) granules of the hand-off
+    tf_u64* fin;                        // [MAX_SEG][ncols][2] the two sums of a long segment, published by the column's owner tile
 };
 
 struct TBwdP {
-    int n_level, n_layers, train, mode;
+    int n_level, n_layers, train, mode, two_hop_nt;
     uint32_t seed, thr; float keep_scale;
     TBLayer L[AREAD_MAX_LEVEL][AREAD_MAX_LAYER];
     int n_t[AREAD_MAX_LEVEL], mask_off[AREAD_MAX_LEVEL], gate_off[AREAD_MAX_LEVEL];
@@ -226,7 +227,42 @@ __global__ __launch_bounds__(TF_THREADS) void k_tower_bwd(const TBwdP p) {
             }
             TB_STAMP();                                      // act backward + arrive
             // ---- B. segment sums ---------------------------------------------------------------------------------------------
-            if (sync_stats) {
+            if (sync_stats && nt > p.two_hop_nt) {
+                TB_STAMP();                                  // poll
+                // long segment: two hops (tower_fused.h): tile i owns the columns c = i (mod nt), one wave per owned column adds the nt
+                // partial pairs (lane = tile, then a butterfly, lower lane first) and publishes the sums; every tile reads ncols pairs
+                const int ti = tile - t0, wv = tid >> 6, ln = tid & 63;
+                for (int cc = ti + nt * wv; cc < ncols; cc += nt * TF_WAVES) {       // (wave-uniform)
+                    if (!act[cc / out_w]) continue;
+                    float t1 = 0.f, t2 = 0.f;
+                    for (int t = ln; t < nt; t += 64) {
+                        float x1 = 0.f, x2 = 0.f;
+                        for (unsigned spins = 0; !tf_get_tagged(L.tags + ((int64_t)(t0 + t) * ncols + cc) * 2, x1, x2);) {
+                            __builtin_amdgcn_s_sleep(1);
+                            if (++spins > TF_SPIN_LIMIT) { __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                        }
+                        t1 += x1; t2 += x2;
+                    }
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const float u1 = __shfl_xor(t1, o), u2 = __shfl_xor(t2, o);
+                        const bool hi = (ln & o) != 0;
+                        t1 = hi ? u1 + t1 : t1 + u1;
+                        t2 = hi ? u2 + t2 : t2 + u2;
+                    }
+                    if (ln == 0) tf_put_tagged(L.fin + ((int64_t)seg * ncols + cc) * 2, t1, t2);
+                }
+                for (int cc = tid; cc < ncols; cc += TF_THREADS) {
+                    float t1 = 0.f, t2 = 0.f;
+                    if (act[cc / out_w])
+                        for (unsigned spins = 0; !tf_get_tagged(L.fin + ((int64_t)seg * ncols + cc) * 2, t1, t2);) {
+                            __builtin_amdgcn_s_sleep(1);
+                            if (++spins > TF_SPIN_LIMIT) { __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                        }
+                    s_m1[cc] = t1 * inv_n; s_m2[cc] = t2 * inv_n;
+                }
+                __syncthreads();
+            } else if (sync_stats) {
                 TB_STAMP();                                  // poll
                 // item = (column, tile group q of nqg): plain sums in tile order inside a group, groups combined in order
                 const int nqg = 4 * ncols <= TF_THREADS ? 4 : 2 * ncols <= TF_THREADS ? 2 : 1;
@@ -236,30 +272,26 @@ __global__ __launch_bounds__(TF_THREADS) void k_tower_bwd(const TBwdP p) {
                     const int cc = item % ncols, q = item / ncols;
                     float t1 = 0.f, t2 = 0.f;
                     if (item < nqg * ncols && act[cc / out_w]) {
-                        float b1[TF_MERGE_Q], b2[TF_MERGE_Q];
-                        bool have[TF_MERGE_Q];
+                        // TF_MERGE_Q partials of the item in flight per round (a one-domain batch of 128 tiles takes three rounds),
+                        // summed in tile order whatever the round size
+                        for (int ib = 0; q + nqg * ib < nt; ib += TF_MERGE_Q) {
+                            float b1[TF_MERGE_Q], b2[TF_MERGE_Q];
+                            bool have[TF_MERGE_Q];
 #pragma unroll
-                        for (int i = 0; i < TF_MERGE_Q; ++i) { b1[i] = 0.f; b2[i] = 0.f; have[i] = q + nqg * i >= nt; }
-                        for (unsigned spins = 0;;) {             // sweep this item's granules until every tag matches
-                            bool all = true;
+                            for (int i = 0; i < TF_MERGE_Q; ++i) { b1[i] = 0.f; b2[i] = 0.f; have[i] = q + nqg * (ib + i) >= nt; }
+                            for (unsigned spins = 0;;) {         // sweep this round's granules until every tag matches
+                                bool all = true;
 #pragma unroll
-                            for (int i = 0; i < TF_MERGE_Q; ++i) {
-                                if (!have[i]) have[i] = tf_get_tagged(L.tags + ((int64_t)(t0 + q + nqg * i) * ncols + cc) * 2, b1[i], b2[i]);
-                                all = all && have[i];
-                            }
-                            if (all) break;
-                            __builtin_amdgcn_s_sleep(1);
-                            if (++spins > TF_SPIN_LIMIT) { __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                        }
-#pragma unroll
-                        for (int i = 0; i < TF_MERGE_Q; ++i) { t1 += b1[i]; t2 += b2[i]; }
-                        for (int t = q + nqg * TF_MERGE_Q; t < nt; t += nqg) {
-                            float x1 = 0.f, x2 = 0.f;
-                            for (unsigned spins = 0; !tf_get_tagged(L.tags + ((int64_t)(t0 + t) * ncols + cc) * 2, x1, x2);) {
+                                for (int i = 0; i < TF_MERGE_Q; ++i) {
+                                    if (!have[i]) have[i] = tf_get_tagged(L.tags + ((int64_t)(t0 + q + nqg * (ib + i)) * ncols + cc) * 2, b1[i], b2[i]);
+                                    all = all && have[i];
+                                }
+                                if (all) break;
                                 __builtin_amdgcn_s_sleep(1);
                                 if (++spins > TF_SPIN_LIMIT) { __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                             }
-                            t1 += x1; t2 += x2;
+#pragma unroll
+                            for (int i = 0; i < TF_MERGE_Q; ++i) { t1 += b1[i]; t2 += b2[i]; }
                         }
                     }
                     if (item < nqg * ncols) { s_c1[q * 256 + cc] = t1; s_c2[q * 256 + cc] = t2; }

@@ -167,6 +167,10 @@ class Adam(torch.optim.Optimizer):
         c.step = int(step)
         return c
 
+    def zero_grad(self, set_to_none: bool = True):
+        """the optimizer holds exactly the model's parameters: the model's zero_grad keeps its gradient bookkeeping exact"""
+        self.model.zero_grad(set_to_none=set_to_none)
+
     # ---- checkpointing (run.py:459-484 stores optimizer.state_dict(); harness.is_continuable does the same) -------------
     def state_dict(self):
         """torch's layout ({'state', 'param_groups'}) with the moments where they really live: 'state' holds the two flat
@@ -228,7 +232,7 @@ class Adam(torch.optim.Optimizer):
             cfg = self._cfg(self._t_table)
             L.check(lib.aread_adam_step(L.ptr(table.data), L.ptr(g), L.ptr(self._m_table), L.ptr(self._v_table), table.numel(),
                                         None, C.byref(cfg), L.stream()))
-        present = np.array([p.grad is not None for p in m._dparams], dtype=bool)
+        present = m._grad_presence()
         if present.any():
             if self._m_dense is None:
                 self._m_dense, self._v_dense = torch.zeros_like(m.dense), torch.zeros_like(m.dense)

@@ -44,7 +44,7 @@ def _run(model, x, y, md, fused, names, fused_bwd=None):
     return out
 
 
-@pytest.mark.parametrize("dropout,B", [(0.0, 700), (0.2, 3000)])
+@pytest.mark.parametrize("dropout,B", [(0.0, 700), (0.2, 3000), (0.2, 5200)])      # 5200: a 51-tile segment (two-hop statistics merge)
 def test_fused_towers_match_layerwise_training_step(dropout, B):
     import aread_amd
     spec = spec_full(dropout=dropout)
@@ -75,7 +75,7 @@ def test_fused_towers_match_layerwise_training_step(dropout, B):
         assert d <= 5e-4 * np.abs(a[k]).max() + 1e-9, (k, d)
 
 
-@pytest.mark.parametrize("dropout,B,p_active", [(0.0, 700, 0.6), (0.2, 3000, 0.6), (0.2, 1500, 0.3)])
+@pytest.mark.parametrize("dropout,B,p_active", [(0.0, 700, 0.6), (0.2, 3000, 0.6), (0.2, 1500, 0.3), (0.2, 5200, 0.6)])
 def test_fused_tower_backward_matches_layerwise(dropout, B, p_active):
     """csrc/tower_fused_bwd.h against the layer-by-layer backward on the same (fused) forward: every buffer the side stream
     and the expert backward read -- dH of every tower layer, the gate-logit gradients, dX, dlin -- and the final gradients."""
@@ -228,14 +228,16 @@ def test_fused_towers_random_batches(seed):
         assert d <= 1e-3 * np.abs(a[k]).max() + 1e-9, (k, d)
 
 
-def test_fused_act_bn_backward_matches_two_pass():
+@pytest.mark.parametrize("B", [2500, 5200])
+def test_fused_act_bn_backward_matches_two_pass(B):
     """k_act_bn_bwd (dropout/ReLU backward + BatchNorm backward of an expert layer in one launch, segment sums handed off in the
-    kernel through data-tagged granules) against the two-kernel sequence: identical gradients up to summation order."""
+    kernel through data-tagged granules) against the two-kernel sequence: identical gradients up to summation order.
+    B = 5200: the largest segment has 51 tiles and takes the two-hop merge (owner tile per granule), the others the flat one."""
     import aread_amd
     from aread_amd import _lib as L
     spec = spec_full(dropout=0.2)
     rng = np.random.default_rng(31)
-    x, y = _batch(spec, rng, 2500)
+    x, y = _batch(spec, rng, B)
     masks = [O.random_valid_mask(spec, rng, 0.6) for _ in range(spec.n_domain)]
     model, P = build_model(spec, 77, precision="bf16x3")
     model.train()

@@ -360,3 +360,56 @@ def test_fused_adam_follows_an_in_place_mask_change():
             assert float((a.dense.data[off:off + n] - b.dense.data[off:off + n]).abs().max()) <= 5e-5, name
     dd = (a.dense.data - b.dense.data).abs()
     assert float(dd.mean()) <= 2e-7 and int((dd > 5e-5).sum()) <= dd.numel() // 2000
+
+
+def test_gradient_bookkeeping_matches_a_full_scan_of_the_parameters():
+    """The module keeps a record of which dense parameters hold a gradient it assigned (so that a backward does not read
+    ~300 `.grad` attributes three times).  The same scripted sequence -- model.zero_grad(), an optimizer's zero_grad() behind
+    the module's back, zero_grad(set_to_none=False), two backwards without zeroing in between (accumulation), masks that
+    change which towers take part -- must leave the same None-pattern and the same gradient values as the mode that reads
+    every attribute (AREAD._GRAD_SCAN)."""
+    import aread_amd
+    from tests.test_gpu_aread import tmask
+    fn, mk, seed = U.GOLDEN_MODELS["full"]
+    G, spec = U.load_golden(fn), mk()
+    crit = torch.nn.BCELoss()
+
+    def loss_of(model, mname):
+        p = f"single_{mname}"
+        d = int(G[f"{p}/domain"])
+        masks = U.golden_masks(spec, G, mname)
+        x = torch.from_numpy(G[f"{p}/x"]).cuda()
+        y = torch.from_numpy(G[f"{p}/y"].astype(np.float32)).cuda()
+        preds = model(x, mode="domain_mask_bagging", domain_i=d, current_mask=tmask(masks[d]))
+        return sum(crit(pr, y) for pr in preds.unbind(dim=0)) / preds.shape[0] + model.get_regularization_loss(device="cuda")
+
+    def script(scan):
+        aread_amd.AREAD._GRAD_SCAN = scan
+        try:
+            model, _ = U.build_model(spec, seed, dropout=0.0)
+            model.train()
+            topt = torch.optim.SGD(model.parameters(), lr=0.0)
+            snaps = []
+
+            def snap():
+                torch.cuda.synchronize()
+                snaps.append([None if p.grad is None else p.grad.detach().cpu().numpy().copy() for p in model.dense_params])
+            model.zero_grad(); loss_of(model, "sparse").backward(); snap()              # 0: fresh, few towers
+            model.zero_grad(); loss_of(model, "ones").backward(); snap()                # 1: fresh, every tower
+            topt.zero_grad(set_to_none=True); loss_of(model, "rand").backward(); snap() # 2: zeroed behind the module's back
+            loss_of(model, "sparse").backward(); snap()                                 # 3: accumulation onto 2
+            model.zero_grad(set_to_none=False); loss_of(model, "sparse").backward(); snap()   # 4: zeroed in place
+            model.zero_grad(); loss_of(model, "sparse").backward(); loss_of(model, "ones").backward(); snap()   # 5: two in a row
+            model.dense_params[0].grad = None                                           # an external edit of one gradient ...
+            topt.zero_grad(set_to_none=True); loss_of(model, "rand").backward(); snap() # 6: ... followed by an external zero_grad
+            return snaps
+        finally:
+            aread_amd.AREAD._GRAD_SCAN = False
+
+    ref, got = script(True), script(False)
+    for k, (a, b) in enumerate(zip(ref, got)):
+        assert [x is None for x in a] == [x is None for x in b], f"snapshot {k}: different None pattern"
+        for i, (x, z) in enumerate(zip(a, b)):
+            if x is not None:
+                np.testing.assert_array_equal(z, x, err_msg=f"snapshot {k}, parameter {i}")
+    assert any(x is None for x in ref[0]) and sum(x is None for x in ref[0]) > sum(x is None for x in ref[1])

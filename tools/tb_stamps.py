@@ -12,7 +12,8 @@ rng = np.random.default_rng(0)
 model = presets.build_model(spec, "cuda", precision="bf16x3"); model.train()
 masks = presets.random_masks(model, 0.7, seed=2000)
 md = aread_amd.pack_masks(masks, 25, model.edge_num, "cuda")
-x, y = synth.amazon_batch(spec, rng, 8192)
+# `one` on the command line: every sample in one domain (the reference's per-domain batches: one segment of 128 tiles)
+x, y = synth.amazon_batch(spec, rng, 8192, domain=3) if "one" in sys.argv[1:] else synth.amazon_batch(spec, rng, 8192)
 xs, ys = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
 bufs = model.make_step_buffers(8192)
 L.check(L.lib().aread_debug_set(b"tf_stamps", 2))
