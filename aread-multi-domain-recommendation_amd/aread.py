@@ -135,6 +135,14 @@ class _AreadFn(torch.autograd.Function):
         finally:
             st.call.grads_init = 0
         model._accumulate_dense(grads, ctx.present, take=True, in_arena=in_place)
+        # The table gradient.  When the regulariser's node of the SAME backward pass has already produced its dense 2*l2*W (it runs
+        # first: it was added to the loss last), the looked-up rows are scatter-added into THAT buffer and this node contributes
+        # nothing of its own: no zero-filled 178 MB buffer and no 178 MB addition by the autograd engine per step.
+        pend = model.__dict__.get("_gtab_pending")
+        if pend is not None and tuple(pend.shape) == ctx.table_shape and pend.device == de.device:
+            model.__dict__["_gtab_pending"] = None          # (the engine may then take the buffer as .grad without a copy)
+            model.embedding.scatter_grad(st.x, de, pend, st.plan.sample_row)
+            return None, None, None, None, None, None
         gtab = torch.zeros(ctx.table_shape, dtype=torch.float32, device=de.device)
         model.embedding.scatter_grad(st.x, de, gtab, st.plan.sample_row)
         return gtab, None, None, None, None, None
@@ -170,6 +178,9 @@ class _RegFn(torch.autograd.Function):
             model._accumulate_dense(arena, model._reg_present, take=True, in_arena=True)
         else:
             model._accumulate_dense(model._l2_coef2(table.device) * model.dense * g, model._reg_present, take=True)
+        # offered to the forward's node of this backward pass (see _AreadFn.backward); withdrawn when the pass ends
+        model.__dict__["_gtab_pending"] = gtab
+        torch.autograd.Variable._execution_engine.queue_callback(model._drop_pending_table_grad)
         return gtab, None, None
 
 
@@ -421,6 +432,9 @@ class AREAD(HempMixin, nn.Module):
                 return False
         self.__dict__["_ghave"] = 0
         return True
+
+    def _drop_pending_table_grad(self):
+        self.__dict__["_gtab_pending"] = None
 
     def _grad_presence(self):
         """bool array: which dense parameters hold a gradient right now (what an optimizer's `p.grad is None` test sees)"""

@@ -374,14 +374,15 @@ def test_gradient_bookkeeping_matches_a_full_scan_of_the_parameters():
     G, spec = U.load_golden(fn), mk()
     crit = torch.nn.BCELoss()
 
-    def loss_of(model, mname):
+    def loss_of(model, mname, reg=True):
         p = f"single_{mname}"
         d = int(G[f"{p}/domain"])
         masks = U.golden_masks(spec, G, mname)
         x = torch.from_numpy(G[f"{p}/x"]).cuda()
         y = torch.from_numpy(G[f"{p}/y"].astype(np.float32)).cuda()
         preds = model(x, mode="domain_mask_bagging", domain_i=d, current_mask=tmask(masks[d]))
-        return sum(crit(pr, y) for pr in preds.unbind(dim=0)) / preds.shape[0] + model.get_regularization_loss(device="cuda")
+        bce = sum(crit(pr, y) for pr in preds.unbind(dim=0)) / preds.shape[0]
+        return bce + model.get_regularization_loss(device="cuda") if reg else bce
 
     def script(scan):
         aread_amd.AREAD._GRAD_SCAN = scan
@@ -393,7 +394,9 @@ def test_gradient_bookkeeping_matches_a_full_scan_of_the_parameters():
 
             def snap():
                 torch.cuda.synchronize()
-                snaps.append([None if p.grad is None else p.grad.detach().cpu().numpy().copy() for p in model.dense_params])
+                tg = model.embedding.embedding_dict.weight.grad
+                snaps.append([None if p.grad is None else p.grad.detach().cpu().numpy().copy() for p in model.dense_params]
+                             + [None if tg is None else tg.detach().cpu().numpy().copy()])
             model.zero_grad(); loss_of(model, "sparse").backward(); snap()              # 0: fresh, few towers
             model.zero_grad(); loss_of(model, "ones").backward(); snap()                # 1: fresh, every tower
             topt.zero_grad(set_to_none=True); loss_of(model, "rand").backward(); snap() # 2: zeroed behind the module's back
@@ -402,6 +405,11 @@ def test_gradient_bookkeeping_matches_a_full_scan_of_the_parameters():
             model.zero_grad(); loss_of(model, "sparse").backward(); loss_of(model, "ones").backward(); snap()   # 5: two in a row
             model.dense_params[0].grad = None                                           # an external edit of one gradient ...
             topt.zero_grad(set_to_none=True); loss_of(model, "rand").backward(); snap() # 6: ... followed by an external zero_grad
+            # the regulariser alone offers its table gradient to a forward node that never comes; the next pass must not see it
+            model.zero_grad(); model.get_regularization_loss(device="cuda").backward(); snap()            # 7
+            model.zero_grad(); loss_of(model, "rand", reg=False).backward(); snap()                        # 8: no regulariser in the loss
+            assert model.__dict__.get("_gtab_pending") is None
+            (0.5 * loss_of(model, "ones")).backward(); snap()                                              # 9: scaled loss, accumulated onto 8
             return snaps
         finally:
             aread_amd.AREAD._GRAD_SCAN = False

@@ -7,7 +7,7 @@ import aread_amd
 from aread_amd import presets
 from tools import synth
 
-steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+steps = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 40
 B = 8192
 spec = presets.amazon_workload(0.2)
 rng = np.random.default_rng(0)
@@ -37,7 +37,7 @@ _timed(model.embedding, "scatter_grad", "  embedding.scatter_grad")
 _lib_bwd = _A.L.lib().aread_backward
 crit = torch.nn.BCELoss()
 hyper = dict(lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-8)
-for name in ("aread_amd.Adam", "torch.optim.Adam"):
+for name in (("aread_amd.Adam",) if "ours" in sys.argv[1:] else ("aread_amd.Adam", "torch.optim.Adam")):
     opt = torch.optim.Adam(model.parameters(), **hyper) if name == "torch.optim.Adam" else aread_amd.Adam(model, **hyper)
     T = {}
 
