@@ -907,7 +907,10 @@ class AREAD(HempMixin, nn.Module):
         if prepared is not None:
             if prepared.n_seg != n_seg or prepared.x.data_ptr() != x.data_ptr():
                 raise ValueError("train_step: the PreparedBatch belongs to another batch / segment layout")
-            main.wait_event(prepared.ready)
+            # a wait on an event that has already completed still costs the main stream ~5 us: the plan was queued a whole step ago
+            # on the idle prefetch stream, so it usually HAS completed by the time the host gets here -- ask before waiting
+            if torch.cuda.is_current_stream_capturing() or not prepared.ready.query():
+                main.wait_event(prepared.ready)
             plan = prepared.plan
             presort = False                            # the index sort is part of the prepared batch
         if plan is None:                               # first on the main stream: everything else waits for it, and it is
