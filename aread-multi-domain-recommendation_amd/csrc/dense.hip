@@ -294,6 +294,8 @@ static int tower_fused_fwd(Ctx& x, bool want_gates) {
     TFwdP p = {};
     p.n_level = cfg.n_level; p.n_layers = m->towers[0].n_layers; p.train = c->train; p.mode = c->mode;
     p.two_hop_nt = two_hop_nt();
+    // the latency-bound tower kernel raises its waves' issue priority over the streaming table-L2 sweep that shares its CUs (-3..10 us per step)
+    { static int pr = -1; if (pr < 0) { const char* e = getenv("AREAD_TOWER_PRIO"); pr = e ? atoi(e) : 1; } p.prio = pr; }
     p.seed = c->drop_seed; p.thr = x.thr; p.keep_scale = x.keep_scale;
     for (int l = 0; l < cfg.n_level; ++l) {
         p.n_t[l] = cfg.n_tower[l]; p.mask_off[l] = m->mask_off[l]; p.gate_off[l] = m->gate_off[l];
@@ -403,6 +405,8 @@ static int tower_fused_bwd(Ctx& x, float* grads) {
     TBwdP p = {};
     p.n_level = cfg.n_level; p.n_layers = m->towers[0].n_layers; p.train = c->train; p.mode = c->mode;
     p.two_hop_nt = two_hop_nt();
+    // the latency-bound tower kernel raises its waves' issue priority over the streaming table-L2 sweep that shares its CUs (-3..10 us per step)
+    { static int pr = -1; if (pr < 0) { const char* e = getenv("AREAD_TOWER_PRIO"); pr = e ? atoi(e) : 1; } p.prio = pr; }
     p.seed = c->drop_seed; p.thr = x.thr; p.keep_scale = x.keep_scale;
     for (int l = 0; l < cfg.n_level; ++l) {
         p.n_t[l] = cfg.n_tower[l]; p.mask_off[l] = m->mask_off[l]; p.gate_off[l] = m->gate_off[l];
@@ -819,7 +823,7 @@ static int layer_bwd(Ctx& x, const LayerL& L, const LayerWs& lw, const float* in
             g.B = x.ws + lw.wT;
             g.ldb = (shared || L.G == 1) ? L.ncols : L.out_dim;
             g.b_gs = (shared || L.G == 1) ? 0 : (int64_t)L.in_dim * L.out_dim;
-            TRY(launch_gemm_bf3(g, x.st));
+                    TRY(launch_gemm_bf3(g, x.st));
         } else TRY(launch_gemm(g, true, false, x.st));   // inactive towers contribute dH = 0
     }
     // wgrad: dW = dH^T in

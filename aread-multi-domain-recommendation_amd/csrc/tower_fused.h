@@ -68,7 +68,7 @@ struct TFLayer {
 };
 
 struct TFwdP {
-    int n_level, n_layers, train, mode, two_hop_nt;
+    int n_level, n_layers, train, mode, two_hop_nt, prio;
     uint32_t seed, thr; float keep_scale;
     TFLayer L[AREAD_MAX_LEVEL][AREAD_MAX_LAYER];
     int n_t[AREAD_MAX_LEVEL], mask_off[AREAD_MAX_LEVEL], gate_off[AREAD_MAX_LEVEL];
@@ -125,6 +125,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_tower_fwd(const TFwdP p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fk = lane >> 4;
     const int tile = blockIdx.x;
+    if (p.prio) __builtin_amdgcn_s_setprio(3);
     const int seg = p.r.tile_seg[tile];
     if (seg < 0) return;                                   // unused tile: takes part in no hand-off
     const int nvalid = p.r.tile_valid[tile];
