@@ -49,7 +49,7 @@ class Call(C.Structure):
                 ("l2_table", C.c_void_p), ("l2_n", C.c_int64), ("l2_coef", C.c_float), ("l2_workgroups", C.c_int32),
                 ("l2_grad", C.c_void_p), ("l2_partial", C.c_void_p), ("l2_reg_out", C.c_void_p), ("l2_dense_coef", C.c_void_p),
                 ("grads_init", C.c_int32), ("init_grads", C.c_void_p), ("init_reg_out", C.c_void_p), ("de_rw", C.c_void_p),
-                ("inference", C.c_int32)]
+                ("inference", C.c_int32), ("drop_seed_dev", C.c_void_p)]
 
 
 for _n, _r, _a in [
@@ -333,6 +333,7 @@ class AREAD(HempMixin, nn.Module):
         self._train_step_owner = False
         self._de_split = False
         self.drop_seed = None          # set to an int to pin the dropout stream (tests)
+        self.drop_seed_dev = None      # device_dropout_seed(): the seed lives in device memory (graph replays draw new masks)
         self._marks = None             # tools/step_anatomy.py: list collecting (name, event) at the step's host-level boundaries
         self._register_state_dict_hook(AREAD._sd_hook)
         self._register_load_state_dict_pre_hook(self._load_hook)
@@ -685,6 +686,7 @@ class AREAD(HempMixin, nn.Module):
         call.update_running, call.domain = int(train), int(domain if domain is not None else 0)
         call.drop_seed = ((self.drop_seed_base + self._drop_calls * 0x9E3779B1) if self.drop_seed is None
                           else int(self.drop_seed)) & 0xFFFFFFFF
+        call.drop_seed_dev = L.ptr(self.drop_seed_dev) if self.drop_seed_dev is not None else None
         call.masks = L.ptr(masks_dev)
         call.params, call.stats, call.nbt = L.ptr(self.dense), L.ptr(self.bn_stats), L.ptr(self.bn_nbt)
         call.ws, call.probs, call.gate_stats = L.ptr(ws), L.ptr(probs), L.ptr(gate)
@@ -854,6 +856,17 @@ class AREAD(HempMixin, nn.Module):
             pb.ready = torch.cuda.Event()
             pb.ready.record(pf)
         return pb
+
+    _SEED_STEP = 0x9E3779B1 - (1 << 32)     # the host-side seed sequence's increment, as an int32
+
+    def device_dropout_seed(self, seed=0):
+        """Keep the dropout seed in device memory (aread_call.drop_seed_dev) from now on: the kernels read it at run time and
+        train_step advances it at its end ON THE STREAM, so a step captured into a hipGraph draws a new dropout mask on every
+        replay (a host-side seed is a kernel argument and would be baked into the capture).  Returns the int32[1] tensor
+        (assign to it to pin a value); `model.drop_seed_dev = None` goes back to the host-side sequence."""
+        self.drop_seed_dev = torch.tensor([int(seed) - (1 << 32) if int(seed) >= (1 << 31) else int(seed)], dtype=torch.int32,
+                                          device=self.dense.device)
+        return self.drop_seed_dev
 
     def _mark(self, name):
         """diagnostics only (tools/step_anatomy.py): a timing event on the current stream when a collector is installed"""
@@ -1030,6 +1043,8 @@ class AREAD(HempMixin, nn.Module):
             self.step_finish(bufs)
             torch.add(bufs["loss"][:1], bufs["reg"][:1], out=bufs["total"])
         self._mark("join parameter gradients + dense L2 + total")
+        if self.drop_seed_dev is not None and self.training and self.dropout > 0:
+            self.drop_seed_dev.add_(self._SEED_STEP)        # (behind every reader of this step's value, stream-ordered; captured with the step)
         if set_grads:
             for p in self._dparams:
                 p.grad = None

@@ -86,6 +86,8 @@ __host__ __device__ static inline bool drop_keep(uint32_t row_key, uint32_t site
     uint32_t c = site * 4096u + col;
     return mix32(row_key ^ (c * 0x85EBCA77u)) >= thr;
 }
+// the dropout seed of a launch: the word in device memory when the caller gave one (aread_call.drop_seed_dev), else the argument
+__device__ __forceinline__ uint32_t drop_seed_of(uint32_t seed, const uint32_t* seed_dev) { return seed_dev ? *seed_dev : seed; }
 static inline uint32_t drop_threshold(float p) {
     double t = (double)p * 4294967296.0;
     t = t + 0.5;

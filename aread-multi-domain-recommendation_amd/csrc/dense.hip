@@ -146,7 +146,7 @@ static int layer_fwd(Ctx& x, const LayerL& L, const LayerWs& lw, const float* in
     a.rmean = x.c->stats + L.rmean; a.rvar = x.c->stats + L.rvar;
     a.gamma = x.params + L.gamma; a.beta = x.params + L.beta;
     a.ncols = L.ncols; a.h = L.out_dim; a.level = level; a.stack = L.stack; a.layer = L.layer; a.train = x.c->train;
-    a.seed = x.c->drop_seed; a.thr = x.thr; a.keep_scale = x.keep_scale; a.r = x.r; a.mp = x.mp;
+    a.seed = x.c->drop_seed; a.seed_dev = x.c->drop_seed_dev; a.thr = x.thr; a.keep_scale = x.keep_scale; a.r = x.r; a.mp = x.mp;
     LAUNCH(k_bn_act, dim3(x.n_tiles, cdiv(L.ncols, 64)), dim3(256), a);
     return AREAD_OK;
 }
@@ -296,7 +296,7 @@ static int tower_fused_fwd(Ctx& x, bool want_gates) {
     p.two_hop_nt = two_hop_nt();
     // the latency-bound tower kernel raises its waves' issue priority over the streaming table-L2 sweep that shares its CUs (-3..10 us per step)
     { static int pr = -1; if (pr < 0) { const char* e = getenv("AREAD_TOWER_PRIO"); pr = e ? atoi(e) : 1; } p.prio = pr; }
-    p.seed = c->drop_seed; p.thr = x.thr; p.keep_scale = x.keep_scale;
+    p.seed = c->drop_seed; p.seed_dev = c->drop_seed_dev; p.thr = x.thr; p.keep_scale = x.keep_scale;
     for (int l = 0; l < cfg.n_level; ++l) {
         p.n_t[l] = cfg.n_tower[l]; p.mask_off[l] = m->mask_off[l]; p.gate_off[l] = m->gate_off[l];
         p.In[l] = ws + x.w.In[l];
@@ -407,7 +407,7 @@ static int tower_fused_bwd(Ctx& x, float* grads) {
     p.two_hop_nt = two_hop_nt();
     // the latency-bound tower kernel raises its waves' issue priority over the streaming table-L2 sweep that shares its CUs (-3..10 us per step)
     { static int pr = -1; if (pr < 0) { const char* e = getenv("AREAD_TOWER_PRIO"); pr = e ? atoi(e) : 1; } p.prio = pr; }
-    p.seed = c->drop_seed; p.thr = x.thr; p.keep_scale = x.keep_scale;
+    p.seed = c->drop_seed; p.seed_dev = c->drop_seed_dev; p.thr = x.thr; p.keep_scale = x.keep_scale;
     for (int l = 0; l < cfg.n_level; ++l) {
         p.n_t[l] = cfg.n_tower[l]; p.mask_off[l] = m->mask_off[l]; p.gate_off[l] = m->gate_off[l];
         p.prevAct[l] = l > 0 ? ws + x.w.tw[l - 1][m->towers[l - 1].n_layers - 1].Act : nullptr;
@@ -779,7 +779,7 @@ static int layer_bwd(Ctx& x, const LayerL& L, const LayerWs& lw, const float* in
     a.d = d; a.H = ws + lw.H; a.mean = ws + lw.mean; a.rstd = ws + lw.rstd;
     a.gamma = x.params + L.gamma; a.beta = x.params + L.beta; a.bpart = ws + lw.bpart;
     a.ncols = L.ncols; a.h = L.out_dim; a.level = level; a.stack = L.stack; a.layer = L.layer; a.train = x.c->train;
-    a.seed = x.c->drop_seed; a.thr = x.thr; a.keep_scale = x.keep_scale; a.r = x.r; a.mp = x.mp;
+    a.seed = x.c->drop_seed; a.seed_dev = x.c->drop_seed_dev; a.thr = x.thr; a.keep_scale = x.keep_scale; a.r = x.r; a.mp = x.mp;
     // wide layers: both passes in one launch with the segment sums handed off inside the kernel (k_act_bn_bwd); the
     // workgroups that wait for each other sit next to each other in dispatch order, 2 x n_tiles resident ones suffice
     // With the drain + counter + poll hand-off this was +40 us per step (2432 workgroups stalling ~5 us each); with data-tagged

@@ -326,7 +326,7 @@ struct ActBwdP {
     float* d; const float* H; const float* mean; const float* rstd; const float* gamma; const float* beta;
     float* bpart;                       // [n_tiles][ncols][2]
     int ncols, h, level, stack, layer, train;
-    uint32_t seed, thr; float keep_scale;
+    uint32_t seed, thr; float keep_scale; const uint32_t* seed_dev;
     RowsP r; ModeP mp;
 };
 
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void k_act_bwd(const ActBwdP p) {
             const float4 dv = *dp;
             const float4 hv = *(const float4*)(p.H + row * p.ncols + c);
             float d[4] = {dv.x, dv.y, dv.z, dv.w}, hh[4] = {hv.x, hv.y, hv.z, hv.w};
-            const uint32_t key = (p.train && p.thr) ? drop_row_key(p.seed, (uint32_t)p.r.row_sample[row]) : 0u;
+            const uint32_t key = (p.train && p.thr) ? drop_row_key(drop_seed_of(p.seed, p.seed_dev), (uint32_t)p.r.row_sample[row]) : 0u;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float xh = (hh[i] - mu[i]) * rs[i];
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(256) void k_act_bn_bwd(const ActBnBwdP q) {
         const int64_t row = (int64_t)tile * TILE_M + rr;
         const float d[4] = {dv[k].x, dv[k].y, dv[k].z, dv[k].w}, hh[4] = {hv[k].x, hv[k].y, hv[k].z, hv[k].w};
         const bool on = act && rr < nvalid;
-        const uint32_t key = (on && p.train && p.thr) ? drop_row_key(p.seed, (uint32_t)p.r.row_sample[row]) : 0u;
+        const uint32_t key = (on && p.train && p.thr) ? drop_row_key(drop_seed_of(p.seed, p.seed_dev), (uint32_t)p.r.row_sample[row]) : 0u;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float x = 0.f, v = 0.f;

@@ -201,7 +201,7 @@ struct BnActP {
     const float* H; float* Act; const float* part; float* mean; float* rstd; float* var;
     const float* rmean; const float* rvar; const float* gamma; const float* beta;
     int ncols, h, level, stack, layer, train;
-    uint32_t seed, thr; float keep_scale;
+    uint32_t seed, thr; float keep_scale; const uint32_t* seed_dev;
     RowsP r; ModeP mp;
 };
 
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void k_bn_act(const BnActP p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) y[i] = y[i] > 0.f ? y[i] : 0.f;
             if (p.train && p.thr) {
-                const uint32_t key = drop_row_key(p.seed, (uint32_t)p.r.row_sample[row]);
+                const uint32_t key = drop_row_key(drop_seed_of(p.seed, p.seed_dev), (uint32_t)p.r.row_sample[row]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) y[i] = drop_keep(key, site, (uint32_t)(cg + i), p.thr) ? y[i] * p.keep_scale : 0.f;
             }

@@ -69,7 +69,7 @@ struct TFLayer {
 
 struct TFwdP {
     int n_level, n_layers, train, mode, two_hop_nt, prio;
-    uint32_t seed, thr; float keep_scale;
+    uint32_t seed, thr; float keep_scale; const uint32_t* seed_dev;
     TFLayer L[AREAD_MAX_LEVEL][AREAD_MAX_LAYER];
     int n_t[AREAD_MAX_LEVEL], mask_off[AREAD_MAX_LEVEL], gate_off[AREAD_MAX_LEVEL];
     const float* X; int n_exp, xw;                       // expert outputs [rows][n_exp*xw]
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_tower_fwd(const TFwdP p) {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
             const int sm = p.r.row_sample[row0 + mi * 16 + fr];
-            dkey[mi] = drop_row_key(p.seed, (uint32_t)sm);
+            dkey[mi] = drop_row_key(drop_seed_of(p.seed, p.seed_dev), (uint32_t)sm);
         }
     }
     for (int t = tid; t < nt && t < TF_MAX_SEG_TILES; t += TF_THREADS) s_tv[t] = (float)p.r.tile_valid[t0 + t];

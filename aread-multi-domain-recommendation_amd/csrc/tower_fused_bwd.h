@@ -29,7 +29,7 @@ struct TBLayer {
 
 struct TBwdP {
     int n_level, n_layers, train, mode, two_hop_nt, prio;
-    uint32_t seed, thr; float keep_scale;
+    uint32_t seed, thr; float keep_scale; const uint32_t* seed_dev;
     TBLayer L[AREAD_MAX_LEVEL][AREAD_MAX_LAYER];
     int n_t[AREAD_MAX_LEVEL], mask_off[AREAD_MAX_LEVEL], gate_off[AREAD_MAX_LEVEL];
     const float* prevAct[AREAD_MAX_LEVEL];               // l > 0: activations of level l-1's last layer [rows][n_t[l-1]*in_w(l)]
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_tower_bwd(const TBwdP p) {
     const uint8_t* masks = mask_lds ? s_mask : gmasks;
     const int ldd = p.ldd;
     const bool drop = p.train && p.thr;
-    if (tid < TILE_M) s_key[tid] = drop ? drop_row_key(p.seed, (uint32_t)p.r.row_sample[row0 + tid]) : 0u;
+    if (tid < TILE_M) s_key[tid] = drop ? drop_row_key(drop_seed_of(p.seed, p.seed_dev), (uint32_t)p.r.row_sample[row0 + tid]) : 0u;
 
     int n_stamp = 0;
 #define TB_STAMP()                                                                                       \

@@ -269,6 +269,11 @@ typedef struct aread_call {
     /* aread_forward, train == 0 only: non-zero = no backward will follow this forward (torch.no_grad evaluation, run.py:712-763):
      * the expert layers apply BatchNorm (running statistics) + ReLU in their GEMM epilogue and do not keep the pre-BatchNorm H. */
     int32_t inference;
+    /* Optional: the dropout seed in DEVICE memory (one uint32).  When set, the kernels read it at run time and `drop_seed` is
+     * ignored -- a step captured in a hipGraph then draws a new dropout mask on every replay if the caller changes the word
+     * between replays (a kernel argument is baked into the capture).  The forward and the backward of one step must see the
+     * same value. */
+    const uint32_t* drop_seed_dev;
 } aread_call;
 
 /* Optional, before the row plan / gather of a step: queues the part of the forward's preparation that depends only on the

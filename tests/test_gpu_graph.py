@@ -82,3 +82,60 @@ def test_graph_replay_equals_eager_step(precision):
             assert torch.equal(bufs["gtable"], r[2]), rep
             assert torch.equal(bufs["probs"], r[3]), rep
             assert torch.equal(model.bn_stats, r[4]), rep
+
+
+def test_graph_replay_draws_a_new_dropout_mask_with_the_device_seed():
+    """ADVICE r1 / VERDICT r2: a host-side dropout seed is a kernel argument, so a captured step replays ONE dropout mask for
+    ever.  With model.device_dropout_seed() the kernels read the seed from device memory and train_step advances it at its
+    end inside the captured work: replay k must equal the eager step run with the k-th value of the sequence pinned."""
+    import aread_amd
+    spec = spec_full(dropout=0.2)
+    rng = np.random.default_rng(5)
+    B = 2000
+    x, y = _batch(spec, rng, B)
+    masks = [O.random_valid_mask(spec, rng, 0.6) for _ in range(spec.n_domain)]
+    model, _ = build_model(spec, 321, precision="bf16x3")
+    model.train()
+    model.domain_mask = [[torch.tensor(np.asarray(m), dtype=torch.bool, device="cuda") for m in mk] for mk in masks]
+    md = aread_amd.pack_masks(masks, spec.n_domain, model.edge_num, "cuda")
+    stats0, nbt0 = model.bn_stats.clone(), model.bn_nbt.clone()
+    xs, ys = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    seed0 = 1234567
+    step_inc = 0x9E3779B1
+
+    def eager(seed):
+        model.drop_seed_dev = None
+        model.drop_seed = seed & 0xFFFFFFFF
+        model.bn_stats.copy_(stats0); model.bn_nbt.copy_(nbt0)
+        bufs = model.make_step_buffers(B)
+        loss = model.train_step(xs, ys, bufs, masks_dev=md, set_grads=False)
+        torch.cuda.synchronize()
+        return loss.clone(), bufs["gdense"].clone()
+
+    ref = [eager(seed0 + k * step_inc) for k in range(3)]
+    assert not torch.equal(ref[0][0], ref[1][0])                 # different seeds really give different masks
+    model.drop_seed = None
+    sd = model.device_dropout_seed(seed0)
+    bufs = model.make_step_buffers(B)
+    step = lambda: model.train_step(xs, ys, bufs, masks_dev=md, set_grads=False)
+    step()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    torch.cuda.synchronize()
+    sd.fill_(seed0)                                              # (warm-up and capture advanced it)
+    for k in range(3):
+        model.bn_stats.copy_(stats0); model.bn_nbt.copy_(nbt0)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(bufs["total"], ref[k][0]), (k, float(bufs["total"]), float(ref[k][0]))
+        assert torch.equal(bufs["gdense"], ref[k][1]), k
+    want = (seed0 + 3 * step_inc) & 0xFFFFFFFF
+    assert (int(sd.item()) & 0xFFFFFFFF) == want
