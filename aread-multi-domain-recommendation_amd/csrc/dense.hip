@@ -225,6 +225,7 @@ static int two_hop_nt() {
     if (g_two_hop_nt < 0) { const char* e = getenv("AREAD_TWO_HOP_NT"); g_two_hop_nt = e ? atoi(e) : TF_TWO_HOP_NT; }
     return g_two_hop_nt;
 }
+static int g_two_hop_nt_ab = -1;   // aread_debug_set("two_hop_nt_act_bn", v): the threshold of k_act_bn_bwd alone (tests: the towers' merge held fixed)
 static int g_fused_act_bn = -1;    // AREAD_FUSED_ACT_BN / aread_debug_set("fused_act_bn", v): k_act_bn_bwd for the expert layers (A/B)
 static int g_n_cu = 0;
 static long long g_fused_fwd_calls = 0, g_fused_bwd_calls = 0;   // aread_debug_get: the tests check that the fused kernels really ran
@@ -792,7 +793,7 @@ static int layer_bwd(Ctx& x, const LayerL& L, const LayerWs& lw, const float* in
         q.a = a; q.cpart = ws + lw.cpart;
         q.tags = (tf_u64*)(ws + lw.tag_b);
         q.fin = (tf_u64*)(ws + lw.fin_b);
-        q.two_hop_nt = two_hop_nt();
+        q.two_hop_nt = g_two_hop_nt_ab >= 0 ? g_two_hop_nt_ab : two_hop_nt();
         q.err = (unsigned*)(ws + x.w.tf_sync) + AREAD_MAX_LEVEL * AREAD_MAX_LAYER * MAX_SEG;
         LAUNCH(k_act_bn_bwd, dim3(x.n_tiles, n_chunks), dim3(256), q);
     } else {
@@ -1076,6 +1077,7 @@ extern "C" int aread_debug_set(const char* key, int value) {
     else if (!strcmp(key, "fused_towers_bwd")) g_fused_bwd = value;
     else if (!strcmp(key, "fused_act_bn")) g_fused_act_bn = value;
     else if (!strcmp(key, "two_hop_nt")) g_two_hop_nt = value;
+    else if (!strcmp(key, "two_hop_nt_act_bn")) g_two_hop_nt_ab = value;
     else if (!strcmp(key, "plan_single")) g_plan_single = value;
     else if (!strcmp(key, "tf_stamps")) g_tf_stamps = value;
     else if (!strcmp(key, "phase_events")) g_phase_on = value;

@@ -140,16 +140,18 @@ def test_fused_towers_other_geometries(geom):
         assert d <= 1e-3 * np.abs(a[k]).max() + 1e-9, (k, d)       # 8-wide towers: two split-bf16 roundings apart
 
 
-@pytest.mark.parametrize("mode", ["wo_mask", "domain_with_mask"])
-def test_fused_towers_dropin_autograd_path(mode):
+@pytest.mark.parametrize("mode,B", [("wo_mask", 900), ("domain_with_mask", 900), ("domain_with_mask", 4500)])
+def test_fused_towers_dropin_autograd_path(mode, B):
     """the drop-in forward()/autograd path (one segment, external dL/dprobs through k_heads_dz, wo_mask = unmasked gates):
-    fused forward + backward against the layer-by-layer kernels on predictions and every gradient."""
+    fused forward + backward against the layer-by-layer kernels on predictions and every gradient.
+    B = 4500: ONE segment of 71 tiles -- the two-hop statistics merge with more tiles than a wave has lanes, in the tower kernels
+    and (expert layers) in k_act_bn_bwd; this is the shape of the reference's per-domain batches."""
     from aread_amd import _lib as L
     spec = spec_full(dropout=0.2)
     rng = np.random.default_rng(17)
-    x, _ = _batch(spec, rng, 900, ragged=False)
+    x, _ = _batch(spec, rng, B, ragged=False)
     x[:, spec.domain_idx] = 2
-    y = torch.from_numpy((rng.random(900) < 0.5).astype(np.float32)).cuda()
+    y = torch.from_numpy((rng.random(B) < 0.5).astype(np.float32)).cuda()
     masks = [O.random_valid_mask(spec, rng, 0.5) for _ in range(spec.n_domain)]
     model, P = build_model(spec, 123, precision="bf16x3")
     model.domain_mask = [[torch.tensor(np.asarray(m), dtype=torch.bool, device="cuda") for m in mk] for mk in masks]
@@ -182,7 +184,15 @@ def test_fused_towers_dropin_autograd_path(mode):
     assert set(ga) == set(gb)
     for n in ga:
         d = np.abs(gb[n] - ga[n]).max()
-        assert d <= 5e-4 * np.abs(ga[n]).max() + 1e-9, (n, d)
+        # (4500 rows: the two-hop merge combines the tile statistics in a tree, the layer-by-layer path in four interleaved chains;
+        # the small gate-weight gradients see that rounding at 1e-3 of their largest element)
+        if B < 1000:
+            assert d <= 5e-4 * np.abs(ga[n]).max() + 1e-9, (n, d)
+        else:
+            rel = float(np.linalg.norm(gb[n] - ga[n]) / (np.linalg.norm(ga[n]) + 1e-30))
+            # (a handful of activations sit within rounding of the ReLU threshold and switch sides between the two statistics orders:
+            # each one changes its gradient contribution wholesale, which the small tensors see at the 1e-3 level)
+            assert (rel <= 2e-2 or d <= 1e-9) and d <= 5e-2 * np.abs(ga[n]).max() + 1e-9, (n, rel, d)
 
 
 @pytest.mark.parametrize("seed", [101, 202, 303, 404, 505, 606])
@@ -228,16 +238,19 @@ def test_fused_towers_random_batches(seed):
         assert d <= 1e-3 * np.abs(a[k]).max() + 1e-9, (k, d)
 
 
-@pytest.mark.parametrize("B", [2500, 5200])
-def test_fused_act_bn_backward_matches_two_pass(B):
+@pytest.mark.parametrize("B,one_domain", [(2500, False), (5200, False), (4500, True)])
+def test_fused_act_bn_backward_matches_two_pass(B, one_domain):
     """k_act_bn_bwd (dropout/ReLU backward + BatchNorm backward of an expert layer in one launch, segment sums handed off in the
     kernel through data-tagged granules) against the two-kernel sequence: identical gradients up to summation order.
-    B = 5200: the largest segment has 51 tiles and takes the two-hop merge (owner tile per granule), the others the flat one."""
+    B = 5200: the largest segment has 51 tiles and takes the two-hop merge (owner tile per granule), the others the flat one;
+    one_domain: every sample in one domain, 71 tiles (more tiles than a wave has lanes: the owner's lanes take two tiles each)."""
     import aread_amd
     from aread_amd import _lib as L
     spec = spec_full(dropout=0.2)
     rng = np.random.default_rng(31)
     x, y = _batch(spec, rng, B)
+    if one_domain:
+        x[:, spec.domain_idx] = 1
     masks = [O.random_valid_mask(spec, rng, 0.6) for _ in range(spec.n_domain)]
     model, P = build_model(spec, 77, precision="bf16x3")
     model.train()
@@ -260,6 +273,71 @@ def test_fused_act_bn_backward_matches_two_pass(B):
     for k in ("gdense", "gtable"):
         d = np.abs(b[k] - a[k]).max()
         assert d <= 1e-4 * np.abs(a[k]).max() + 1e-12, (k, d)
+
+
+@pytest.mark.parametrize("B", [4500, 8192])
+def test_two_hop_statistics_merge_matches_the_flat_merge(B):
+    """Segments of more than AREAD_TWO_HOP_NT tiles merge their BatchNorm statistics (forward) and their (sum dyhat, sum dyhat*xhat)
+    (backward) in two hops -- an owner tile per column / granule, then every tile reads the finished pair -- in k_tower_fwd,
+    k_tower_bwd and k_act_bn_bwd.  Same kernels, same one-domain batch (71 resp. 128 tiles in ONE segment: the reference's
+    per-domain batches), threshold 32 against a threshold no segment reaches.
+    A different summation order moves the statistics by rounding; downstream a few activations within rounding of the ReLU
+    threshold switch sides and, through the segment sums of the BatchNorm backward, move every later gradient at the 1e-3
+    level -- so each merge is checked where its inputs are still identical:
+      towers : every forward buffer, and the LAST tower layer's dH (the first BatchNorm backward: inputs equal to rounding);
+      experts: k_act_bn_bwd's own threshold alone, the towers' merge held fixed -- dH of all three expert layers."""
+    import aread_amd
+    from aread_amd import _lib as L
+    lib = L.lib()
+    spec = spec_full(dropout=0.2)
+    rng = np.random.default_rng(23)
+    x, y = _batch(spec, rng, B, ragged=False)
+    x[:, spec.domain_idx] = 3
+    masks = [O.random_valid_mask(spec, rng, 0.6) for _ in range(spec.n_domain)]
+    model, P = build_model(spec, 55, precision="bf16x3")
+    model.train()
+    model._stats0 = model.bn_stats.clone()
+    model.domain_mask = [[torch.tensor(np.asarray(m), dtype=torch.bool, device="cuda") for m in mk] for mk in masks]
+    md = aread_amd.pack_masks(masks, spec.n_domain, model.edge_num, "cuda")
+    names = [("tw0.0.H", 3 * 64), ("tw0.1.Act", 3 * 32), ("tw1.1.Act", 6 * 16), ("tw2.1.Act", 12 * 8), ("dz", 12), ("tw2.1.dAct", 12 * 8),
+             ("ex2.dAct", 4 * 64), ("ex1.dAct", 4 * 128), ("ex0.dAct", 4 * 256)]
+    FLAT = 1 << 20
+
+    def run(towers, experts):
+        L.check(lib.aread_debug_set(b"two_hop_nt", towers))
+        L.check(lib.aread_debug_set(b"two_hop_nt_act_bn", experts))
+        return _run(model, x, y, md, 1, names)
+
+    def quant(u, v, n):
+        ref, got = u[n][:u["rows"]], v[n][:u["rows"]]
+        nz = ref != 0
+        rel = np.abs(got - ref)[nz] / np.abs(ref)[nz]
+        return float(np.quantile(rel, 0.5)), float(np.quantile(rel, 0.99)), float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+    try:
+        flat, tow, exp = run(FLAT, FLAT), run(32, FLAT), run(FLAT, 32)
+    finally:
+        L.check(lib.aread_debug_set(b"two_hop_nt", 32)); L.check(lib.aread_debug_set(b"two_hop_nt_act_bn", -1))
+    for r in (flat, tow, exp):
+        assert r["err"] == 0 and np.isfinite(r["loss"])
+    # towers, two hops against one: forward + the first BatchNorm backward
+    assert abs(tow["loss"] - flat["loss"]) <= 1e-6 * abs(flat["loss"])
+    np.testing.assert_allclose(tow["probs"], flat["probs"], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(tow["stats"], flat["stats"], rtol=1e-5, atol=1e-7)
+    for n in ("tw0.0.H", "tw0.1.Act", "tw1.1.Act", "tw2.1.Act", "dz", "tw2.1.dAct"):
+        q50, q99, l2 = quant(flat, tow, n)
+        assert q50 <= 2e-5 and q99 <= 2e-3 and l2 <= 1e-4, (n, q50, q99, l2)
+    for k in ("gdense", "gtable"):                       # (everything downstream of the ReLU switches: the 1e-3 level)
+        rel = np.linalg.norm(tow[k] - flat[k]) / np.linalg.norm(flat[k])
+        assert rel <= 1e-2, (k, rel)
+    # experts, two hops against one, identical inputs: more than half of dH's elements have dyhat = 0 and are nothing but
+    # -gamma*rstd*(m1 + xhat*m2), i.e. the segment sums themselves -- a tile missed or counted twice would be 1e-2 everywhere
+    assert exp["loss"] == flat["loss"]
+    for n in ("ex2.dAct", "ex1.dAct", "ex0.dAct"):
+        q50, q99, l2 = quant(flat, exp, n)
+        assert q50 <= 2e-6 and q99 <= 1e-3 and l2 <= 2e-5, (n, q50, q99, l2)
+    for k in ("gdense", "gtable"):
+        rel = np.linalg.norm(exp[k] - flat[k]) / np.linalg.norm(flat[k])
+        assert rel <= 2e-5, (k, rel)
 
 
 def test_fused_towers_eval_and_wo_mask_forward():
