@@ -30,6 +30,7 @@ def _run(model, x, y, md, fused, names, fused_bwd=None):
     L.check(L.lib().aread_debug_set(b"fused_towers_bwd", int(fused if fused_bwd is None else fused_bwd)))
     model.drop_seed = 1234
     bufs = model.make_step_buffers(x.shape[0])
+    bufs["ws"].zero_()                          # (the tests read whole buffers: what a step never writes -- H of a tower no mask reaches -- is 0, not stale memory)
     model.bn_stats.copy_(model._stats0); model.bn_nbt.zero_()
     loss = model.train_step(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), bufs, masks_dev=md, want_gates=True)
     torch.cuda.synchronize()
