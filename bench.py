@@ -526,8 +526,10 @@ def measure_gemm_kernel(model, bufs, L, B, precision):
                 "avg_launch_us": round(t * 1e6, 2), "mfma": "v_mfma_f32_16x16x32_bf16 x3 (hi*hi + hi*lo + lo*hi), f32 accumulate",
                 # the same launch against the HBM roof of its compulsory bytes (A read once + C written once): it sits at the ridge
                 "hbm_frac_compulsory_bytes": round((rows * D + rows * h1) * 4 / t / 1e9 / HBM_PEAK_GBS, 4),
-                "what_bounds_it": "neither roof: with stores, MFMAs, A loads and weight traffic removed 27 of 31 us remain (the k-loop's "
-                                  "LDS reads + fp32->(hi,lo) split + barrier per k-step): profiles/r03_gemm_experiments.txt"}
+                "operand_ingest_gbs": round(((rows // 64) * ((h1 + 127) // 128) * ((D + 31) // 32) * 24576) / t / 1e9, 1),
+                "what_bounds_it": "neither roof: the L2 -> CU operand path.  Every 64 x 128 tile pulls 24 KB of fp32 operands per k-step "
+                                  "(operand_ingest_gbs, chip-wide; the LDS-DMA variants reach 5.7-6.5 TB/s and the same 22-31 us); HBM sees a "
+                                  "fifth of it, the matrix pipe is busy 9 % of the cycles (PMC): profiles/r03_gemm_experiments.txt"}
     fn = lambda: L.check(L.lib().aread_gemm(L.ptr(A), D, 0, 1, L.ptr(W), D, 0, 1, L.ptr(out), h1, 0, L.ptr(bias), 0, rows, h1, D,
                                             1, 0, L.stream()))
     t = _time_kernel(fn)
