@@ -16,6 +16,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_exp(const float* __restrict__ 
     constexpr int NT = 64 * WM * WN, TM = 32 * WM, TN = 32 * FN * WN;
     constexpr int A_EL = TM * 32, W_EL = TN * 32;
     constexpr int UA = (TM * 4 / NT) > 0 ? (TM * 4 / NT) : 1, UAD = (TM * 8 + NT - 1) / NT, UW = (TN * 8 + NT - 1) / NT;
+    constexpr int UWR = (TN * 4 / NT) > 0 ? (TN * 4 / NT) : 1;      // PRESPLIT == 2: W through registers too (fp32 [N][K], split in the kernel)
+    const float* Wf = (const float*)Wimg;
     __shared__ __attribute__((aligned(1024))) char s_lds[NB * 2 * (A_EL + W_EL) * 2];
     __bf16* Ab = (__bf16*)s_lds;
     __bf16* Wb = Ab + NB * 2 * A_EL;
@@ -57,6 +59,28 @@ __global__ __launch_bounds__(64 * WM * WN) void k_exp(const float* __restrict__ 
                 *(bf16x8*)(Ah + o) = h; *(bf16x8*)(Al + o) = l;
             }
         };
+        float4 wv[UWR][2];
+        auto loadW = [&](int s) {
+#pragma unroll
+            for (int u = 0; u < UWR; ++u) {
+                const int idx = tid + u * NT, row = idx >> 2, plane = idx & 3;
+                const float* src = Wf + (int64_t)(bx * TN + row) * K + s * 32 + plane * 8;
+                wv[u][0] = *(const float4*)src; wv[u][1] = *(const float4*)(src + 4);
+            }
+        };
+        auto storeW = [&](int buf) {
+            __bf16* Wh = Wb + buf * 2 * W_EL; __bf16* Wl = Wh + W_EL;
+#pragma unroll
+            for (int u = 0; u < UWR; ++u) {
+                const int idx = tid + u * NT, row = idx >> 2, plane = idx & 3;
+                const float x[8] = {wv[u][0].x, wv[u][0].y, wv[u][0].z, wv[u][0].w, wv[u][1].x, wv[u][1].y, wv[u][1].z, wv[u][1].w};
+                bf16x8 h, l;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { h[e] = (__bf16)x[e]; l[e] = (__bf16)(x[e] - (float)h[e]); }
+                const int o = bf3_off(TN, row, plane);
+                *(bf16x8*)(Wh + o) = h; *(bf16x8*)(Wl + o) = l;
+            }
+        };
         auto dma = [&](const __bf16* img, int s, __bf16* dstb, int el, int pieces, int U) {
             const char* src = (const char*)(img + (int64_t)s * 2 * el);
             char* dst = (char*)dstb;
@@ -68,6 +92,32 @@ __global__ __launch_bounds__(64 * WM * WN) void k_exp(const float* __restrict__ 
             }
         };
         const int a_row = wr * 32 + l31, w_row = wc * 32 * FN + l31;
+        if (PRESPLIT == 2) {
+            // k_gemm_bf3's structure at this tile size: both operands global -> registers (one k-step ahead) -> split -> LDS, one buffer
+            loadA(0); loadW(0);
+            for (int s = 0; s < KS; ++s) {
+                storeA(0); storeW(0);
+                __syncthreads();
+                if (s + 1 < KS) { loadA(s + 1); loadW(s + 1); }
+                const __bf16* Ah = Ab; const __bf16* Al = Ah + A_EL;
+                const __bf16* Wh = Wb; const __bf16* Wl = Wh + W_EL;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int plane = lh + 2 * kk;
+                    const bf16x8 ah = *(const bf16x8*)(Ah + bf3_off(TM, a_row, plane));
+                    const bf16x8 al = *(const bf16x8*)(Al + bf3_off(TM, a_row, plane));
+#pragma unroll
+                    for (int i = 0; i < FN; ++i) {
+                        const bf16x8 wh = *(const bf16x8*)(Wh + bf3_off(TN, w_row + 32 * i, plane));
+                        const bf16x8 wl = *(const bf16x8*)(Wl + bf3_off(TN, w_row + 32 * i, plane));
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc[i], 0, 0, 0);
+                    }
+                }
+                __syncthreads();
+            }
+        } else {
         // prologue: NB-1 stages in flight
         for (int s = 0; s < NB - 1 && s < KS; ++s) {
             dma(wimg, s, Wb + s * 2 * W_EL, W_EL, TN * 8, UW);
@@ -106,6 +156,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_exp(const float* __restrict__ 
                 asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NB - 2) * (UW + UAD)) : "memory");
             }
             __builtin_amdgcn_s_barrier();
+        }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -163,6 +214,14 @@ int main() {
     run<2, 2, 2, 1, 4>("A pre-split, 64x128 tiles, 4 buffers", A, Aimg, Wimg, C, M, 1024, 288, 2);
     run<2, 4, 2, 1, 2>("A pre-split, 64x256 tiles, 8 waves, 2 buf", A, Aimg, Wimg, C, M, 1024, 288, 2);
     run<4, 4, 2, 1, 2>("A pre-split, 128x256 tiles, 16 waves, 2 buf", A, Aimg, Wimg, C, M, 1024, 288, 1);
+    printf("== both operands through registers with the split in the kernel (k_gemm_bf3's structure), by tile size\n");
+    run<2, 2, 2, 2, 1>("reg path,  64x128 tiles, 4 waves", A, Aimg, Wimg, C, M, 1024, 288, 4);
+    run<4, 2, 2, 2, 1>("reg path, 128x128 tiles, 8 waves", A, Aimg, Wimg, C, M, 1024, 288, 2);
+    run<4, 1, 4, 2, 1>("reg path, 128x128 tiles, 4 waves (32x128 each)", A, Aimg, Wimg, C, M, 1024, 288, 2);
+    run<4, 2, 1, 2, 1>("reg path, 128x64 tiles, 8 waves", A, Aimg, Wimg, C, M, 1024, 288, 3);
+    run<4, 4, 1, 2, 1>("reg path, 128x128 tiles, 16 waves", A, Aimg, Wimg, C, M, 1024, 288, 1);
+    run<2, 2, 2, 2, 1>("reg path,  64x128 tiles, dgrad shape", A, Aimg, Wimg, C, M, 256, 1024, 4);
+    run<4, 2, 2, 2, 1>("reg path, 128x128 tiles, dgrad shape", A, Aimg, Wimg, C, M, 256, 1024, 2);
     printf("== expert L1 dgrad shape (N 288 -> 256 here, K 1024)\n");
     run<4, 2, 2, 0, 2>("A converted in flight, 2 buffers", A, Aimg, Wimg, C, M, 256, 1024, 2);
     run<4, 2, 2, 1, 2>("A pre-split by DMA, 2 buffers", A, Aimg, Wimg, C, M, 256, 1024, 2);
