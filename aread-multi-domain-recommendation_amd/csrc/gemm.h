@@ -361,6 +361,23 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm(const GemmP p) {
 // ================================================================================================
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// (hi, lo) of two fp32 values: hi = bf16(x), lo = bf16(x - hi).  Written on pairs so that it compiles to v_cvt_pk_bf16_f32, the pair
+// widened back by shift / mask, ONE packed subtract, v_cvt_pk_bf16_f32: five VALU instructions per pair (the element-wise loop came out
+// at seven for every other pair; -4 % on every split-bf16 GEMM of the step)
+__device__ __forceinline__ void bf3_split2(float x0, float x1, bf16x2& h, bf16x2& l) {
+    const f32x2 x = {x0, x1};
+    h = __builtin_convertvector(x, bf16x2);
+    l = __builtin_convertvector(x - __builtin_convertvector(h, f32x2), bf16x2);
+}
+__device__ __forceinline__ void bf3_split4(const float4& v, bf16x4& h, bf16x4& l) {
+    bf16x2 h0, l0, h1, l1;
+    bf3_split2(v.x, v.y, h0, l0);
+    bf3_split2(v.z, v.w, h1, l1);
+    h = (bf16x4){h0[0], h0[1], h1[0], h1[1]};
+    l = (bf16x4){l0[0], l0[1], l1[0], l1[1]};
+}
 // LDS image of a split-bf16 operand tile [ROWS][32 k]: four k-planes of [ROWS][8 bf16 = one 16-B slot]; plane f keeps
 // row r in slot r ^ (2*f).  With that XOR both the ds_read_b128 fragment reads (16-lane groups {0-3,12-15,20-27}, ...:
 // every group sees all 16 fragment rows once, on two neighbouring planes) and the ds_write_b64 staging stores
@@ -404,13 +421,8 @@ struct Bf3Loader {
             const int idx = tid + p * GEMM_THREADS;
             const int row = idx >> 3, kq = idx & 7;
             if (ROWS * 8 % GEMM_THREADS == 0 || row < ROWS) {
-                const float x[4] = {v[p].x, v[p].y, v[p].z, v[p].w};
                 bf16x4 h, l;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    h[i] = (__bf16)x[i];
-                    l[i] = (__bf16)(x[i] - (float)h[i]);
-                }
+                bf3_split4(v[p], h, l);
                 const int o = bf3_off(ROWS, row, kq >> 1) + 4 * (kq & 1);
                 *(bf16x4*)(hi + o) = h;
                 *(bf16x4*)(lo + o) = l;
@@ -555,13 +567,8 @@ struct Bf3RcLoader {
             const int idx = tid + p * GEMM_THREADS;
             const int krow = idx / Q, mq = idx - krow * Q;
             if ((Q * GEMM_BK) % GEMM_THREADS == 0 || krow < GEMM_BK) {
-                const float x[4] = {v[p].x, v[p].y, v[p].z, v[p].w};
                 bf16x4 h, l;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    h[i] = (__bf16)x[i];
-                    l[i] = (__bf16)(x[i] - (float)h[i]);
-                }
+                bf3_split4(v[p], h, l);
                 const int o = RcImage<ROWS>::off(krow, 4 * mq);
                 *(bf16x4*)(hi + o) = h;
                 *(bf16x4*)(lo + o) = l;

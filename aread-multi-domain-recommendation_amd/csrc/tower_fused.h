@@ -100,9 +100,11 @@ __device__ __forceinline__ void tf_load_sc1(const float* p, float& a, float& b) 
 __device__ __forceinline__ void tf_put8(__bf16* hi, __bf16* lo, int off, const float (&x)[8]) {
     bf16x8 h, l;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        h[e] = (__bf16)x[e];
-        l[e] = (__bf16)(x[e] - (float)h[e]);
+    for (int e = 0; e < 8; e += 2) {
+        bf16x2 h2, l2;
+        bf3_split2(x[e], x[e + 1], h2, l2);
+        h[e] = h2[0]; h[e + 1] = h2[1];
+        l[e] = l2[0]; l[e + 1] = l2[1];
     }
     *(bf16x8*)(hi + off) = h;
     *(bf16x8*)(lo + off) = l;
