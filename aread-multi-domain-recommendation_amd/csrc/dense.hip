@@ -750,6 +750,24 @@ static int flush_wgrads(Ctx& x, bool fork) {
 }
 
 static int flush_reductions(Ctx& x) {
+    static int merge = -1;                                   // AREAD_REDUCE_MERGE=0: two launches (A/B)
+    if (merge < 0) { const char* e = getenv("AREAD_REDUCE_MERGE"); merge = e ? atoi(e) : 1; }
+    if (merge && x.splitk.n > 0 && x.bias.n > 0) {           // both pending: one launch
+        int64_t mx = 0;
+        for (int i = 0; i < x.splitk.n; ++i) {
+            const int64_t e = (int64_t)x.splitk.d[i].G * x.splitk.d[i].M * x.splitk.d[i].N;
+            if (e > mx) mx = e;
+        }
+        int bx = cdiv(mx, 128);
+        if (bx > 2304) bx = 2304;
+        int mc = 0;
+        for (int i = 0; i < x.bias.n; ++i) if (x.bias.d[i].ncols > mc) mc = x.bias.d[i].ncols;
+        if (cdiv(mc, 16) > bx) bx = cdiv(mc, 16);
+        x.bias.r = x.r; x.bias.mp = x.mp;
+        LAUNCH(k_reduce_tail_all, dim3(bx, x.splitk.n + x.bias.n), dim3(256), x.splitk, x.bias);
+        x.splitk.n = 0; x.bias.n = 0;
+        return AREAD_OK;
+    }
     if (x.splitk.n > 0) {
         int64_t mx = 0;
         for (int i = 0; i < x.splitk.n; ++i) {

@@ -178,12 +178,12 @@ __global__ __launch_bounds__(256) void k_transpose_weights(const TransAllP a) {
 struct SplitKOne { const float* slab; float* out; int k_split, G, M, N; int64_t ldo, o_gs; int transposed; };
 #define MAX_WGRADS 24
 struct SplitKAllP { int n; SplitKOne d[MAX_WGRADS]; };
-__global__ __launch_bounds__(256) void k_splitk_reduce_all(const SplitKAllP a) {
+__device__ __forceinline__ void splitk_reduce_body(const SplitKAllP& a, int job) {
     // block = 32 groups of 4 consecutive elements x 8 interleaved slab groups: a thread sums the slabs k = kg, kg+8, ... (four
     // independent 16-byte loads in flight), the 8 partial sums are combined through LDS in a fixed order.  Small weight
     // gradients are cut into many slabs (up to rows/64): the slab loop must not be one serial chain.
     __shared__ float4 s_acc[8][32];
-    const SplitKOne& p = a.d[blockIdx.y];
+    const SplitKOne& p = a.d[job];
     const int64_t per = (int64_t)p.G * p.M * p.N;
     const int el = threadIdx.x & 31, kg = threadIdx.x >> 5;
     const bool vec = (per & 3) == 0 && (p.N & 3) == 0;
@@ -237,16 +237,18 @@ __global__ __launch_bounds__(256) void k_splitk_reduce_all(const SplitKAllP a) {
     }
 }
 
+__global__ __launch_bounds__(256) void k_splitk_reduce_all(const SplitKAllP a) { splitk_reduce_body(a, blockIdx.y); }
+
 // batched per-layer column reductions at the end of the backward (grid.y = layer):
 //   db[c]     = sum over live tiles of cpart[tile][c]
 //   dbeta[c]  = sum over tiles of BatchNorm-applied, active segments of bpart[tile][c][0]
 //   dgamma[c] = ... of bpart[tile][c][1]
 struct BiasOne { const float* cpart; const float* bpart; float* db; float* dgamma; float* dbeta; int ncols, h, level; };
 struct BiasAllP { int n; BiasOne d[MAX_BN_LAYERS_DECL]; RowsP r; ModeP mp; };
-__global__ __launch_bounds__(256) void k_bias_reduce_all(const BiasAllP a) {
+__device__ __forceinline__ void bias_reduce_body(const BiasAllP& a, int job) {
     __shared__ float s_acc[3][16][17];
     __shared__ int s_seg[1024];                  // tile -> segment (or -1), with bit 30 set when the segment's BatchNorm applies
-    const BiasOne& p = a.d[blockIdx.y];
+    const BiasOne& p = a.d[job];
     const int cl = threadIdx.x & 15, tg = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
     if (blockIdx.x * 16 >= p.ncols) return;
@@ -280,6 +282,13 @@ __global__ __launch_bounds__(256) void k_bias_reduce_all(const BiasAllP a) {
         float* o = tg == 0 ? p.db : (tg == 1 ? p.dbeta : p.dgamma);
         o[c] += tot;
     }
+}
+__global__ __launch_bounds__(256) void k_bias_reduce_all(const BiasAllP a) { bias_reduce_body(a, blockIdx.y); }
+// both batches in ONE launch (grid.y = split-K jobs, then the column-reduction jobs): they add into disjoint parts of the gradient
+// buffer and sit at the tail of the side stream's chain, where a launch boundary is ~5 us of the step
+__global__ __launch_bounds__(256) void k_reduce_tail_all(const SplitKAllP a, const BiasAllP b) {
+    if ((int)blockIdx.y < a.n) splitk_reduce_body(a, blockIdx.y);
+    else bias_reduce_body(b, blockIdx.y - a.n);
 }
 
 // ------------------------------------------------------------------------------------------------
