@@ -332,7 +332,9 @@ static inline int rs_passes(int64_t n_rows) {
 //   FINAL : one workgroup sees every entry: all runs go to the table gradient; otherwise the runs that touch the
 //           workgroup's first / last key go to the boundary list (2 entries per workgroup, always both written, sorted).
 // ------------------------------------------------------------------------------------------------
+#ifndef SR_PW
 #define SR_PW 16                       // entries per worker
+#endif
 #define SR_SENT 0x7fffffff             // key of "no entry" (table rows are < 2^31 - 1)
 
 template <bool GATHER, bool FINAL, int THREADS>
