@@ -973,7 +973,9 @@ class AREAD(HempMixin, nn.Module):
         st.call.async_tail = 3          # parameter gradients finish on the library's side stream: see step_finish
         if in_bwd:                      # the table L2 sweep is issued by the backward, beside the latency-bound tower backward
             st.call.l2_table, st.call.l2_n, st.call.l2_coef = L.ptr(table), table.numel(), self.l2_reg_embedding
-            st.call.l2_workgroups = self.l2_pass_workgroups or 256   # one workgroup per CU: leaves room for the tower kernel's
+            st.call.l2_workgroups = self.l2_pass_workgroups or 1024  # four workgroups per CU.  (256 was the choice while the sweep stole issue
+            # slots from the tower kernel it runs beside; since that kernel raises its wave priority the wider sweep is done sooner and
+            # costs it less: 0.7481 -> 0.7421 ms/step, profiles/r03_ab_variants.txt section 15)
             st.call.l2_grad, st.call.l2_partial, st.call.l2_reg_out = L.ptr(gtable), L.ptr(part), L.ptr(bufs["reg"])
         st.call.grads_init = 1 if dense_first else 0      # gdense = 2*coef*w was queued on the library's side stream by aread_prepare
         split_de = self.split_de and self._train_step_owner and bufs.get("de_rw") is not None    # only train_step adds the two shares (other callers read bufs["de"] whole)
