@@ -326,8 +326,12 @@ class AREAD(HempMixin, nn.Module):
         self.l2_pass_early = os.environ.get("AREAD_L2_EARLY", "0") == "1"    # A/B: the sweep right after the row plan (round 1)
         self.l2_pass_in_backward = os.environ.get("AREAD_L2_IN_BWD", "1") == "1"   # default: issued by aread_backward beside the tower backward
         self.sort_early = os.environ.get("AREAD_SORT_EARLY", "0") == "1"                  # A/B: index sort issued before the forward (graph replay: +10 us)
-        self.prepare_early = os.environ.get("AREAD_PREPARE_EARLY", "1") == "1"            # aread_prepare ahead of the row plan (A/B: 0 = inside aread_forward)
-        self.l2_dense_first = os.environ.get("AREAD_L2_DENSE_FIRST", "1") == "1"          # dense L2 terms at the head of train_step (A/B: 0 = at its tail)
+        # aread_prepare ahead of the row plan, and with it the dense L2 terms at the head of train_step (gradient buffer initialised with
+        # them): both were wins while the step's tail waited for the side stream; with the tail balanced they cost the head more than
+        # they save (0.7353 -> 0.7226 ms/step with both off, profiles/r03_ab_variants.txt section 16).  Off by default: the preparation
+        # forks inside aread_forward, the dense L2 terms are formed with the step's total in the last launch.
+        self.prepare_early = os.environ.get("AREAD_PREPARE_EARLY", "0") == "1"
+        self.l2_dense_first = os.environ.get("AREAD_L2_DENSE_FIRST", "1") == "1"          # (only with AREAD_PREPARE_EARLY=1)
         self._dense_l2_done_first = False
         self.split_de = os.environ.get("AREAD_SPLIT_DE", "1") == "1"                      # row-wise share of dL/de in its own buffer (A/B: 0 = accumulated into de)
         self._train_step_owner = False
