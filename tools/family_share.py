@@ -9,7 +9,7 @@ fam = [("split-bf16 GEMM (k_gemm_bf3*, forward / dgrad / wgrad)", r"k_gemm_bf3")
        ("fused tower pyramid (k_tower_fwd, k_tower_bwd)", r"k_tower_"), ("BatchNorm / activation (k_bn_act, k_act_bn_bwd, k_act_bwd, k_bn_bwd_apply, k_bn_running)", r"k_bn_|k_act_bwd|k_act_bn_bwd"),
        ("embedding (gather, radix sort, segmented reduce)", r"k_embed|k_rs_|k_segreduce"), ("L2 regularisation (k_l2_*)", r"k_l2_"),
        ("row plan (k_plan_*)", r"k_plan_"), ("row-wise trunk (cross network, linear, group embedding)", r"k_rowwise|k_grp_|k_seg_reduce"),
-       ("split-K / bias reductions", r"k_splitk|k_bias_reduce|k_reduce_tiles|k_colsum"),
+       ("split-K / bias reductions", r"k_splitk|k_bias_reduce|k_reduce_tiles|k_reduce_tail|k_colsum"),
        ("per-step preparation (mask tables, weight images, transposes, memsets, copies)", r"k_mask_prep|k_prep_wimg|k_transpose|rocclr|k_loss_finish|k_step_total")]
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 out = {"source": f"rocprofv3 --kernel-trace --stats -- python bench.py --step-only --no-graph ({int(steps)} steps)", "sum_of_kernel_us_per_step": round(tot / 1e3 / steps, 1),
