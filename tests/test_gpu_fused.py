@@ -341,6 +341,34 @@ def test_two_hop_statistics_merge_matches_the_flat_merge(B):
         assert rel <= 2e-5, (k, rel)
 
 
+def test_prepare_early_and_dense_l2_first_give_the_default_steps_bits():
+    """aread_prepare ahead of the row plan (model.prepare_early) with the dense L2 terms initialising the gradient buffer
+    (aread_call.init_grads / grads_init) is off by default since the end of round 3 (it costs the head of the step more than it
+    saves) but stays part of the C ABI: same loss, probabilities and gradients, bit for bit, as the default order."""
+    import aread_amd
+    spec = spec_full(dropout=0.2)
+    rng = np.random.default_rng(8)
+    x, y = _batch(spec, rng, 2200)
+    masks = [O.random_valid_mask(spec, rng, 0.6) for _ in range(spec.n_domain)]
+    model, P = build_model(spec, 21, precision="bf16x3")
+    model.train()
+    model._stats0 = model.bn_stats.clone()
+    model.domain_mask = [[torch.tensor(np.asarray(m), dtype=torch.bool, device="cuda") for m in mk] for mk in masks]
+    md = aread_amd.pack_masks(masks, spec.n_domain, model.edge_num, "cuda")
+    res = []
+    try:
+        for early, first in ((False, False), (True, True), (True, False)):
+            model.prepare_early, model.l2_dense_first = early, first
+            res.append(_run(model, x, y, md, 1, []))
+    finally:
+        model.prepare_early, model.l2_dense_first = False, True
+    a = res[0]
+    for b in res[1:]:
+        assert b["err"] == 0 and b["loss"] == a["loss"]
+        for k in ("probs", "gdense", "gtable", "stats"):
+            np.testing.assert_array_equal(b[k], a[k], err_msg=k)
+
+
 def test_fused_towers_eval_and_wo_mask_forward():
     """eval mode (running statistics, no hand-off) and the unmasked warm-up mode through the drop-in forward()."""
     from aread_amd import _lib as L
